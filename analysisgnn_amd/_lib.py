@@ -1,0 +1,119 @@
+"""ctypes binding of libagnn_hip.so (include/agnn.h).  No CPU fallback: missing library or
+non-GPU tensors raise.  PyTorch is used only for device memory and the current HIP stream."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libagnn_hip.so")
+MAX_SEG = 32
+
+SPMM_MEAN, SPMM_SKIP_SELF, SPMM_ACCUM = 1, 2, 4
+INT32_MAX = 2 ** 31 - 1
+
+
+class AgnnError(RuntimeError):
+    pass
+
+
+class CooSeg(C.Structure):
+    _fields_ = [("row", C.c_void_p), ("col", C.c_void_p), ("etype", C.c_void_p),
+                ("etype_code", C.c_int64), ("n_edges", C.c_int64), ("n_rows", C.c_int64)]
+
+
+class Rel(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("rowptr", C.c_void_p), ("rowend", C.c_void_p), ("col", C.c_void_p),
+                ("ew", C.c_void_p), ("colscale", C.c_void_p), ("ld_src", C.c_int64)]
+
+
+_lib: Optional[C.CDLL] = None
+
+# every exported symbol of include/agnn.h: (name, restype, argtypes)
+SIGNATURES = {
+    "agnn_last_error": (C.c_char_p, []),
+    "agnn_version": (C.c_int, []),
+    "agnn_csr_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "agnn_csr_build": (C.c_int, [C.c_int, C.POINTER(CooSeg), C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_size_t, C.c_void_p]),
+    "agnn_csr_rowend": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "agnn_spmm_f32": (C.c_int, [C.c_int, C.POINTER(Rel), C.c_int64, C.c_int32, C.c_void_p, C.c_int64,
+                                C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_uint32,
+                                C.c_void_p]),
+}
+
+
+def load() -> C.CDLL:
+    """Load the HIP library or raise (the product path never degrades to a CPU implementation)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AgnnError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C analysisgnn_amd/csrc`). analysisgnn_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().agnn_last_error()
+        raise AgnnError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def require_gpu(*tensors: Optional[torch.Tensor]) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise AgnnError("analysisgnn_amd ops need tensors on a HIP device (no CPU fallback); "
+                            f"got a tensor on {t.device}")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise AgnnError(f"tensors on different devices: {dev} vs {t.device}")
+    if dev is None:
+        raise AgnnError("no tensor given")
+    return dev
+
+
+def stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def f32c(t: torch.Tensor) -> torch.Tensor:
+    """fp32 with unit inner stride and 16-byte aligned rows (copies only when necessary)."""
+    if t.dtype != torch.float32:
+        raise AgnnError(f"fp32 expected, got {t.dtype}")
+    if t.dim() != 2:
+        raise AgnnError(f"2-D feature matrix expected, got shape {tuple(t.shape)}")
+    if t.stride(1) != 1 or t.stride(0) % 4 != 0 or t.data_ptr() % 16 != 0 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t
+
+
+def make_rels(items: Sequence[dict]):
+    arr = (Rel * len(items))()
+    for i, it in enumerate(items):
+        arr[i].src = it["src"]
+        arr[i].rowptr = it["rowptr"]
+        arr[i].rowend = it.get("rowend")
+        arr[i].col = it["col"]
+        arr[i].ew = it.get("ew")
+        arr[i].colscale = it.get("colscale")
+        arr[i].ld_src = it["ld_src"]
+    return arr

@@ -1,0 +1,126 @@
+/*
+ * agnn.h — C-ABI of libagnn_hip.so: the MI355X (gfx950) kernels behind the AnalysisGNN
+ * heterogeneous message-passing hot path.
+ *
+ * The reference (manoskary/analysisgnn) is 100 % Python and has no FFI of its own; its hot path
+ * bottoms out in three third-party operator families.  Each entry point below replaces one of
+ * them, and the Python host side (analysisgnn_amd/_lib.py, ctypes) is the only caller:
+ *
+ *   agnn_csr_build        the per-relation `edge_index[:, edge_type == r]` compaction and the
+ *                         COO bookkeeping that torch_scatter / PyG redo on every call
+ *                         (ref: analysisgnn/models/core/hgnn.py:137-139, :481-483)
+ *   agnn_csr_rowend       PyG `trim_to_layer` edge narrowing (ref: models/cadence.py:167-173)
+ *   agnn_spmm_f32         `h[edge_index[1]]` gather + `torch_scatter.scatter(..., reduce=sum|mean,
+ *                         out=...)` (ref: core/gnn.py:70-74, :511, :539; core/hgnn.py:406-407;
+ *                         models/analysis.py:580-586) and PyG `SAGEConv` mean aggregation under
+ *                         `HeteroConv` (ref: models/cadence.py:147-159,174)
+ *   agnn_hgt_attn_*       PyG `HGTConv` message/softmax/aggregate (reached through graphmuse
+ *                         `HybridHGT`, ref: models/analysis.py:445-453)
+ *   agnn_gated_spmm_*     `ResGatedGraphConv` edge gate + scatter (ref: core/gnn.py:246-257)
+ *
+ * Conventions (all entry points)
+ *   - plain pointers and sizes only; every `const T*`/`T*` marked (device) is device memory owned
+ *     by the caller (PyTorch's caching allocator); arrays marked (host) are read during the call.
+ *   - all work is enqueued on `stream`; no implicit synchronisation, no default-stream use, no
+ *     allocation, no global mutable state: safe to call from several host threads and under
+ *     hipGraph capture.
+ *   - return 0 on success, a negative errno-style code otherwise (AGNN_E*); the message is
+ *     available from agnn_last_error() (thread-local).  Nothing is printed, nothing throws.
+ *   - feature matrices are fp32, row-major, rows 16-byte aligned, H % 4 == 0.
+ *   - index arrays produced by the library are int32; COO inputs are int64 as PyTorch holds them.
+ *   - sums run in a fixed order (CSR order = original edge order inside a row): results are
+ *     bitwise reproducible; no float atomics anywhere.
+ */
+#ifndef AGNN_H_
+#define AGNN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* agnn_stream_t; /* hipStream_t */
+
+#define AGNN_OK        0
+#define AGNN_EINVAL  (-22) /* bad shape / size / flag combination */
+#define AGNN_EALIGN  (-14) /* misaligned pointer or leading dimension */
+#define AGNN_ENOMEM  (-12) /* workspace too small */
+#define AGNN_ERUNTIME (-5) /* HIP runtime error */
+
+#define AGNN_MAX_SEG 32    /* segments (relations x directions) per call */
+
+const char* agnn_last_error(void);
+/* library / ABI version: (major << 16) | minor */
+int agnn_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * CSR construction.  A "segment" is one relation in one direction: edges (row_e, col_e),
+ * e < n_edges, grouped by row.  If `etype` is non-NULL only edges with etype[e] == etype_code
+ * take part (the in-tree layers' `edge_type == code` mask, hgnn.py:138).
+ * Output (device):
+ *   rowstart [total_rows + 1]  with total_rows = sum_s n_rows[s];  segment s owns the slice
+ *            rowstart + rowbase[s] (n_rows[s] + 1 entries, rowbase = exclusive prefix of n_rows);
+ *            entries are offsets into col/perm shared by all segments.
+ *   col      [E_total]  column (gathered row) id of every kept edge, grouped by row,
+ *   perm     [E_total]  original edge position e inside its segment's COO arrays.
+ * Inside a row, edges keep their original order (stable) so perm is increasing there.
+ * E_total = sum_s n_edges[s] is the capacity; slots past the number of kept edges are undefined.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const int64_t* row;    /* (device) [n_edges] */
+  const int64_t* col;    /* (device) [n_edges] */
+  const int64_t* etype;  /* (device) [n_edges] or NULL */
+  int64_t etype_code;
+  int64_t n_edges;
+  int64_t n_rows;
+} agnn_coo_seg_t;
+
+size_t agnn_csr_workspace_bytes(int64_t e_total, int64_t total_rows);
+
+int agnn_csr_build(int n_seg, const agnn_coo_seg_t* segs /* (host) */,
+                   int32_t* rowstart, int32_t* col, int32_t* perm,
+                   void* workspace, size_t workspace_bytes, agnn_stream_t stream);
+
+/* rowend[i] = first position p in [rowptr[i], rowptr[i+1]) with perm[p] >= e_limit (or
+ * rowptr[i+1]): the row's edges restricted to the COO prefix [0, e_limit) — PyG trim_to_layer. */
+int agnn_csr_rowend(const int32_t* rowptr, const int32_t* perm, int64_t n_rows, int64_t e_limit,
+                    int32_t* rowend, agnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-relation segmented gather-reduce ("hetero SpMM").  For every output row i < n_rows and
+ * relation r < n_rel:
+ *     acc_r(i) = sum_{p in [rowptr_r[i], end_r(i))}  w_r(p) * src_r[ col_r[p], 0:H ]
+ *     w_r(p)   = (ew_r ? ew_r[p] : 1) * (colscale_r ? colscale_r[col_r[p]] : 1) * valid(p)
+ *     valid(p) = !(SKIP_SELF && col==i) && col < col_limit
+ *     cnt_r(i) = number of valid p
+ *     val_r(i) = (acc_r(i) + (self ? self[i] : 0)) * (MEAN ? 1 / max(cnt_r(i), 1) : 1)
+ * and out[i*ld_out + r*rel_stride + 0:H] (=|+=) val_r(i); with rel_stride == 0 all relations
+ * add into the same slot (first one obeys `accumulate`).  `self` reproduces torch_scatter's
+ * `out=x.clone()` numerator.  inv_cnt (optional, [n_rel, n_rows]) receives
+ * 1/max(cnt,1) for the backward pass.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* src;        /* (device) [n_src, ld_src] */
+  const int32_t* rowptr;   /* (device) [n_rows + 1] */
+  const int32_t* rowend;   /* (device) [n_rows] or NULL */
+  const int32_t* col;      /* (device) base shared with rowptr's offsets */
+  const float* ew;         /* (device) per-position weights or NULL */
+  const float* colscale;   /* (device) [n_src] or NULL */
+  int64_t ld_src;
+} agnn_rel_t;
+
+#define AGNN_SPMM_MEAN      1u
+#define AGNN_SPMM_SKIP_SELF 2u
+#define AGNN_SPMM_ACCUM     4u
+
+int agnn_spmm_f32(int n_rel, const agnn_rel_t* rels /* (host) */, int64_t n_rows, int32_t H,
+                  float* out, int64_t ld_out, int64_t rel_stride,
+                  const float* self, int64_t ld_self,
+                  float* inv_cnt, int32_t col_limit, uint32_t flags, agnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGNN_H_ */

@@ -1,0 +1,175 @@
+"""Kernel-level parity on a real MI355X: HIP C-ABI (libagnn_hip.so) vs the plain-C oracle.
+Integer outputs (CSR) must be identical; fp32 sums follow the same operation order as the oracle
+(fmaf in CSR order, true division), tolerance 1e-6 relative (observed: bitwise or 1 ulp)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import c_oracle  # noqa: E402
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _build(segs_np):
+    from analysisgnn_amd.graph import SegSpec, build_csr
+    dev = _dev()
+    specs = []
+    for s in segs_np:
+        specs.append(SegSpec(row=torch.from_numpy(s["row"]).to(dev), col=torch.from_numpy(s["col"]).to(dev),
+                             n_rows=s["n_rows"],
+                             etype=(torch.from_numpy(s["etype"]).to(dev) if s.get("etype") is not None else None),
+                             code=s.get("code", 0)))
+    return build_csr(specs)
+
+
+def _check_csr(segs_np):
+    csrs = _build(segs_np)
+    rs, c, p, kept = c_oracle.csr_build(segs_np)
+    base = 0
+    for s, csr in zip(segs_np, csrs):
+        n = s["n_rows"]
+        rp = csr.rowptr.cpu().numpy()
+        assert np.array_equal(rp, rs[base:base + n + 1])
+        base += n
+    assert np.array_equal(csrs[0].col.cpu().numpy()[:kept], c[:kept])
+    assert np.array_equal(csrs[0].perm.cpu().numpy()[:kept], p[:kept])
+    return csrs
+
+
+@pytest.mark.parametrize("n,e", [(1, 0), (5, 0), (7, 1), (64, 1000), (500, 3305), (16000, 105760)])
+def test_csr_build_single(n, e):
+    rng = np.random.default_rng(n + e)
+    _check_csr([dict(row=rng.integers(0, n, size=e).astype(np.int64),
+                     col=rng.integers(0, n, size=e).astype(np.int64), n_rows=n)])
+
+
+def test_csr_build_many_segments_with_type_mask_and_empty_relation():
+    rng = np.random.default_rng(5)
+    n, e = 300, 5000
+    row = rng.integers(0, n, size=e).astype(np.int64)
+    col = rng.integers(0, n, size=e).astype(np.int64)
+    et = rng.integers(0, 5, size=e).astype(np.int64)
+    segs = [dict(row=row, col=col, n_rows=n, etype=et, code=k) for k in range(7)]      # codes 5,6 empty
+    segs += [dict(row=col, col=row, n_rows=n, etype=et, code=k) for k in range(7)]
+    _check_csr(segs)
+
+
+def test_csr_build_skewed_rows_and_out_of_range():
+    rng = np.random.default_rng(6)
+    n, e = 50, 4000
+    row = np.where(rng.random(e) < 0.7, 3, rng.integers(0, n, size=e)).astype(np.int64)   # one heavy row
+    row[:5] = n + 10                                                                      # dropped
+    col = rng.integers(0, n, size=e).astype(np.int64)
+    _check_csr([dict(row=row, col=col, n_rows=n)])
+
+
+def test_rowend_matches_oracle():
+    rng = np.random.default_rng(7)
+    n, e = 200, 3000
+    seg = dict(row=rng.integers(0, n, size=e).astype(np.int64), col=rng.integers(0, n, size=e).astype(np.int64), n_rows=n)
+    csr = _build([seg])[0]
+    rs, c, p, _ = c_oracle.csr_build([seg])
+    for lim in (0, 1, 1234, e - 1):
+        got = csr.rowend(lim).cpu().numpy()[:n]
+        assert np.array_equal(got, c_oracle.csr_rowend(rs, p, lim))
+    assert csr.rowend(e) is None and csr.rowend(None) is None
+
+
+def _spmm_case(n_dst, n_src, es, H, mean, shared, with_self, skip_self=False, col_limit=None, trim=None, seed=0,
+               colscale=False):
+    from analysisgnn_amd import _lib, ops
+    dev = _dev()
+    rng = np.random.default_rng(seed)
+    R = len(es)
+    segs = [dict(row=rng.integers(0, n_dst, size=e).astype(np.int64),
+                 col=rng.integers(0, n_src, size=e).astype(np.int64), n_rows=n_dst) for e in es]
+    csrs = _build(segs)
+    rs, c, p, kept = c_oracle.csr_build(segs)
+    srcs = [rng.standard_normal((n_src, H)).astype(np.float32) for _ in range(R)]
+    x = rng.standard_normal((n_dst, H)).astype(np.float32) if with_self else None
+    cs = [rng.random(n_src).astype(np.float32) + 0.5 for _ in range(R)] if colscale else [None] * R
+    n_rows = n_dst
+    orels, grels, keep = [], [], []
+    base = 0
+    for r in range(R):
+        rp = rs[base:base + n_dst + 1]
+        base += n_dst
+        re_o = c_oracle.csr_rowend(rp, p, trim[r]) if trim else None
+        orels.append(dict(src=srcs[r], rowptr=rp, col=c, rowend=re_o, colscale=cs[r]))
+        st = torch.from_numpy(srcs[r]).to(dev)
+        re_g = csrs[r].rowend(trim[r]) if trim else None
+        cst = torch.from_numpy(cs[r]).to(dev) if colscale else None
+        keep += [st, re_g, cst]
+        grels.append(dict(src=st.data_ptr(), rowptr=csrs[r].rowptr.data_ptr(), rowend=_lib.ptr(re_g),
+                          col=csrs[r].col.data_ptr(), colscale=_lib.ptr(cst), ld_src=st.stride(0)))
+    lim = col_limit if col_limit is not None else 2 ** 31 - 1
+    exp, inv_o = c_oracle.spmm(orels, n_rows, H, 0 if shared else H, self_=x, mean=mean, skip_self=skip_self,
+                               col_limit=lim, want_inv_cnt=True)
+    out = torch.full((n_rows, H if shared else R * H), float("nan"), device=dev)
+    inv = torch.empty((R, n_rows), device=dev)
+    xt = torch.from_numpy(x).to(dev) if with_self else None
+    flags = (_lib.SPMM_MEAN if mean else 0) | (_lib.SPMM_SKIP_SELF if skip_self else 0)
+    ops._launch(grels, n_rows, H, out, 0 if shared else H, xt, inv, lim, flags)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert not np.isnan(got).any()
+    np.testing.assert_allclose(got, exp, rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(inv.cpu().numpy(), inv_o)
+    return float(np.abs(got - exp).max())
+
+
+@pytest.mark.parametrize("H", [4, 8, 64, 256, 260, 512, 1024])
+def test_spmm_widths(H):
+    _spmm_case(97, 97, [400, 150], H, mean=True, shared=False, with_self=True, seed=H)
+
+
+@pytest.mark.parametrize("mean", [True, False])
+@pytest.mark.parametrize("shared", [True, False])
+@pytest.mark.parametrize("with_self", [True, False])
+def test_spmm_modes(mean, shared, with_self):
+    _spmm_case(300, 211, [1200, 0, 37, 900], 32, mean, shared, with_self, seed=11, colscale=shared)
+
+
+def test_spmm_heavy_row_and_empty_rows():
+    # one destination with > 64 neighbours (several col batches), many rows without any edge
+    from analysisgnn_amd import _lib
+    _spmm_case(40, 500, [3000], 256, mean=True, shared=False, with_self=False, seed=3)
+
+
+def test_spmm_filters_and_trim():
+    _spmm_case(120, 120, [900], 16, mean=True, shared=True, with_self=True, skip_self=True, col_limit=70, seed=5)
+    _spmm_case(120, 120, [900, 400], 16, mean=True, shared=False, with_self=False, trim=[300, 0], seed=6)
+
+
+def test_spmm_c2_shape_against_oracle():
+    """BASELINE config C2 shape for one layer (32 x 500 notes, 4 relations, H=256) vs the C oracle."""
+    from analysisgnn_amd.synth import make_batch
+    from analysisgnn_amd.graph import HeteroIndex
+    from analysisgnn_amd import ops
+    dev = _dev()
+    b = make_batch(32, 500)
+    N = b.num_nodes["note"]
+    eid = {et: torch.from_numpy(e).to(dev) for et, e in b.edge_index.items()}
+    hix = HeteroIndex(eid, {"note": N})
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(N, 256, generator=g)
+    xd = x.to(dev).requires_grad_(True)
+    ets = list(eid.keys())
+    spec = ops.AggSpec(fwd=[hix.fwd[et] for et in ets], bwd=[hix.bwd[et] for et in ets], src_id=[0] * 4, n_rows=N,
+                       mean=True, shared_slot=False)
+    out = ops.aggregate(spec, [xd])
+    segs = [dict(row=b.edge_index[et][1], col=b.edge_index[et][0], n_rows=N) for et in ets]
+    rs, c, p, _ = c_oracle.csr_build(segs)
+    exp = c_oracle.spmm([dict(src=x.numpy(), rowptr=rs[r * N:(r + 1) * N + 1], col=c) for r in range(4)], N, 256, 256)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), exp, rtol=1e-6, atol=1e-6)
+    # backward = transposed gather with 1/deg(dst) weights; property: <A x, g> == <x, A^T g>
+    gout = torch.randn(N, 1024, generator=g).to(dev)
+    out.backward(gout)
+    lhs = float((out.detach().double() * gout.double()).sum())
+    rhs = float((xd.detach().double() * xd.grad.double()).sum())
+    assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs))
