@@ -1,0 +1,270 @@
+"""Drop-in encoders with the constructor / forward surface the reference calls
+(analysisgnn/models/analysis.py:444-473 constructors, :576-579 forward; legacy positional forms
+models/chord.py:590,601 and models/pitch_spelling.py:157,221, models/cadence.py:232-234,298-299).
+
+THE BUILD SPEC.  The real classes live in graphmuse (not in the reference tree, unpinned, not
+installable here), so their exact layer wiring cannot be read offline; this file isolates every
+choice that is "parity unpinned" (SURVEY.md App. A.6):
+  * GNN stack = per layer `trim_to_layer` -> HeteroConv{SAGEConv per edge type}(aggr) and, between
+    layers, LayerNorm -> ReLU -> dropout   [in-tree analog: models/cadence.py:142-176]
+  * `aggr` across relations defaults to 'sum' [models/cadence.py:151,158]
+  * HGT stack = PyG HGTConv(heads) layers, ReLU + dropout between layers
+  * hybrid branch = padded 2-layer bi-GRU (hidden H/2) over each subgraph's target notes ->
+    LayerNorm -> MLP, concatenated with the GNN output -> Linear(2H, H)
+    [models/cadence.py:248-303, models/analysis.py:527-537]
+  * use_jk = bi-LSTM JumpingKnowledge over the per-layer target-note outputs [core/gnn.py:345-365]
+  * MetricalGNN = GNN stack + MLP(H -> H -> output_channels)
+Parameter names follow PyG (`convs.<i>.convs.<src___rel___dst>.lin_l/lin_r`, `kqv_lin.lins.<type>` ...)
+so a graphmuse/PyG state_dict can be mapped by name once it can be inspected.
+
+All message passing runs on the C-ABI kernels; dense projections are library GEMMs; nothing
+here has a CPU path.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib, ops
+from .core_layers import JumpingKnowledge
+from .graph import HeteroIndex, hetero_index
+
+EdgeType = Tuple[str, str, str]
+
+
+def et_key(et: EdgeType) -> str:
+    return "<" + "___".join(et) + ">"
+
+
+# ------------------------------------------------------------------------------------------
+# neighbour-mask conventions: per-hop counts, per-element hop index, or None
+# ------------------------------------------------------------------------------------------
+def _hop_counts(mask, keys, num_layers):
+    out = {}
+    for k in keys:
+        if k not in mask:
+            continue
+        m = mask[k]
+        if isinstance(m, torch.Tensor):
+            out[k] = torch.bincount(m, minlength=num_layers + 1).tolist()      # one host sync per batch
+        else:
+            out[k] = [int(v) for v in m]
+    return out
+
+
+class TrimPlan:
+    """Rows / COO prefixes each layer keeps (PyG trim_to_layer applied cumulatively,
+    models/cadence.py:165-173).  With no masks every layer keeps everything."""
+
+    def __init__(self, num_layers, x_dict, edge_index_dict, mask_node, mask_edge):
+        self.n_keep: List[Dict[str, int]] = []
+        self.e_keep: List[Dict[EdgeType, Optional[int]]] = []
+        n = {k: int(v.shape[0]) for k, v in x_dict.items()}
+        e = {k: int(v.shape[1]) for k, v in edge_index_dict.items()}
+        if mask_node is None or mask_edge is None:
+            for _ in range(num_layers):
+                self.n_keep.append(dict(n))
+                self.e_keep.append({k: None for k in e})
+            return
+        nodes = _hop_counts(mask_node, n.keys(), num_layers)
+        edges = _hop_counts(mask_edge, e.keys(), num_layers)
+        for layer in range(num_layers):
+            if layer > 0:
+                for k in n:
+                    if k in nodes:
+                        n[k] -= nodes[k][-layer]
+                for k in e:
+                    if k in edges:
+                        e[k] -= edges[k][-layer]
+            self.n_keep.append(dict(n))
+            self.e_keep.append(dict(e))
+
+
+# ------------------------------------------------------------------------------------------
+# SAGE
+# ------------------------------------------------------------------------------------------
+class SAGEConv(nn.Module):
+    """Parameter holder with PyG SAGEConv defaults (mean aggr, root weight, lin_l bias only)."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin_l = nn.Linear(in_channels, out_channels, bias=True)
+        self.lin_r = nn.Linear(in_channels, out_channels, bias=False)
+
+
+class HeteroConv(nn.Module):
+    """HeteroConv({edge_type: SAGEConv}, aggr) fused per destination type: one multi-relation
+    gather-reduce (mean per relation, written as the [N, R*H] A operand) and two GEMMs
+    (neighbour blocks, pre-summed root blocks)."""
+
+    def __init__(self, edge_types: Sequence[EdgeType], in_channels: int, out_channels: int, aggr: str = "sum"):
+        super().__init__()
+        if aggr not in ("sum", "mean"):
+            raise NotImplementedError(f"aggr={aggr!r}")
+        self.edge_types = [tuple(et) for et in edge_types]
+        self.aggr = aggr
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.convs = nn.ModuleDict({et_key(et): SAGEConv(in_channels, out_channels) for et in self.edge_types})
+
+    def forward(self, x_dict, edge_index_dict, index: Optional[HeteroIndex] = None,
+                n_keep: Optional[Dict[str, int]] = None, e_keep: Optional[Dict[EdgeType, Optional[int]]] = None):
+        if index is None:
+            index = hetero_index(edge_index_dict, {k: int(v.shape[0]) for k, v in x_dict.items()})
+        by_dst: Dict[str, List[EdgeType]] = {}
+        for et in self.edge_types:
+            s, _, d = et
+            if et in index.fwd and s in x_dict and d in x_dict:
+                by_dst.setdefault(d, []).append(et)
+        out = {}
+        for d, ets in by_dst.items():
+            n = n_keep[d] if n_keep is not None else int(x_dict[d].shape[0])
+            src_types: List[str] = []
+            src_id = []
+            for et in ets:
+                if et[0] not in src_types:
+                    src_types.append(et[0])
+                src_id.append(src_types.index(et[0]))
+            spec = ops.AggSpec(fwd=[index.fwd[et] for et in ets], bwd=[index.bwd[et] for et in ets], src_id=src_id,
+                               n_rows=n, mean=True, shared_slot=False,
+                               e_limit=[e_keep[et] for et in ets] if e_keep is not None else None)
+            A = ops.aggregate(spec, [x_dict[s] for s in src_types])                      # [n, R*H]
+            convs = [self.convs[et_key(et)] for et in ets]
+            W_l = torch.cat([c.lin_l.weight for c in convs], dim=1)                       # [out, R*H]
+            b = sum(c.lin_l.bias for c in convs)
+            W_r = sum(c.lin_r.weight for c in convs)
+            y = torch.addmm(F.linear(A, W_l, b), x_dict[d][:n], W_r.t())
+            out[d] = y / len(ets) if self.aggr == "mean" else y
+        return out
+
+
+class HeteroSAGEStack(nn.Module):
+    def __init__(self, edge_types, input_channels, hidden_channels, num_layers, dropout=0.5, aggr="sum"):
+        super().__init__()
+        self.num_layers = num_layers
+        self.dropout = dropout
+        self.convs = nn.ModuleList()
+        self.layer_norms = nn.ModuleList()
+        for i in range(num_layers):
+            self.convs.append(HeteroConv(edge_types, input_channels if i == 0 else hidden_channels, hidden_channels, aggr))
+            if i < num_layers - 1:
+                self.layer_norms.append(nn.LayerNorm(hidden_channels))
+
+    def forward(self, x_dict, edge_index_dict, plan: TrimPlan, collect: Optional[list] = None):
+        index = hetero_index(edge_index_dict, {k: int(v.shape[0]) for k, v in x_dict.items()})
+        for i, conv in enumerate(self.convs):
+            keep = plan.n_keep[i]
+            x_dict = {k: v for k, v in x_dict.items()}
+            x_dict = conv(x_dict, edge_index_dict, index, keep, plan.e_keep[i])
+            if i < self.num_layers - 1:
+                x_dict = {k: F.dropout(F.relu(self.layer_norms[i](v)), self.dropout, self.training)
+                          for k, v in x_dict.items()}
+            if collect is not None:
+                collect.append(x_dict["note"])
+        return x_dict
+
+
+# ------------------------------------------------------------------------------------------
+# hybrid (sequence) branch — MIOpen GRU for now
+# ------------------------------------------------------------------------------------------
+class _HybridMixin:
+    def _init_hybrid(self, input_channels, hidden_channels, num_layers, dropout, use_jk):
+        self.use_jk = bool(use_jk)
+        if self.use_jk:
+            self.jk = JumpingKnowledge(hidden_channels, num_layers)
+        self.rnn = nn.GRU(input_size=input_channels, hidden_size=hidden_channels // 2, num_layers=2,
+                          batch_first=True, bidirectional=True, dropout=dropout)
+        self.rnn_norm = nn.LayerNorm(hidden_channels)
+        self.rnn_mlp = nn.Sequential(nn.Linear(hidden_channels, hidden_channels), nn.ReLU(),
+                                     nn.LayerNorm(hidden_channels), nn.Dropout(dropout),
+                                     nn.Linear(hidden_channels, hidden_channels))
+        self.cat_proj = nn.Linear(hidden_channels * 2, hidden_channels)
+
+    def hybrid_forward(self, x, batch):
+        lengths = torch.bincount(batch)
+        lens = lengths.tolist()
+        if len(set(lens)) == 1:                     # equal windows (the usual batch): a view, no padding
+            y = x.view(len(lens), lens[0], x.shape[1])
+            y, _ = self.rnn(y)
+            y = self.rnn_mlp(self.rnn_norm(y))
+            return y.reshape(-1, y.shape[-1])
+        seqs = nn.utils.rnn.pad_sequence(x.split(lens), batch_first=True, padding_value=0.0)
+        y, _ = self.rnn(seqs)
+        y = self.rnn_mlp(self.rnn_norm(y))
+        return torch.cat(nn.utils.rnn.unpad_sequence(y, batch_first=True, lengths=lengths.cpu()), dim=0)
+
+    def _finish(self, x_note, outs, x_in, batch_dict, batch_size):
+        x = x_note[:batch_size]
+        if self.use_jk:
+            x = self.jk([o[:batch_size] for o in outs])
+        if batch_dict is None:
+            batch_note = torch.zeros(batch_size, dtype=torch.long, device=x.device)
+        else:
+            batch_note = batch_dict["note"][:batch_size]
+        z = self.hybrid_forward(x_in[:batch_size], batch_note)
+        return self.cat_proj(torch.cat((x, z), dim=-1))
+
+
+class HybridGNN(nn.Module, _HybridMixin):
+    """analysis.py:455-462 constructor; forward keywords analysis.py:576-579; legacy positional
+    order (x_dict, edge_index_dict, batch_dict, batch_size, masks...) chord.py:601."""
+
+    def __init__(self, metadata=None, input_channels=None, hidden_channels=None, num_layers=2, dropout=0.5,
+                 use_jk=False, aggr="sum", edge_types=None, **kwargs):
+        super().__init__()
+        if metadata is None:
+            if edge_types is None:
+                raise TypeError("HybridGNN needs metadata=(node_types, edge_types)")
+            nodes = sorted({t for et in edge_types for t in (et[0], et[2])})
+            metadata = (nodes, list(edge_types))          # older signature, models/chord.py:590
+        self.metadata = (list(metadata[0]), [tuple(e) for e in metadata[1]])
+        self.num_layers = num_layers
+        self.gnn = HeteroSAGEStack(self.metadata[1], input_channels, hidden_channels, num_layers, dropout, aggr)
+        self._init_hybrid(input_channels, hidden_channels, num_layers, dropout, use_jk)
+
+    def forward(self, x_dict, edge_index_dict, batch_dict=None, batch_size=None, neighbor_mask_node=None,
+                neighbor_mask_edge=None, return_edge_index=False, edge_attr_dict=None):
+        _lib.require_gpu(*x_dict.values())
+        if batch_size is None:
+            batch_size = int(x_dict["note"].shape[0])
+        plan = TrimPlan(self.num_layers, x_dict, edge_index_dict, neighbor_mask_node, neighbor_mask_edge)
+        outs: list = []
+        h = self.gnn(x_dict, edge_index_dict, plan, outs)
+        out = self._finish(h["note"], outs, x_dict["note"], batch_dict, batch_size)
+        return (out, edge_index_dict) if return_edge_index else out
+
+
+class MetricalGNN(nn.Module):
+    """analysis.py:464-473 (keywords), pitch_spelling.py:157 (positional), cadence.py:232-234."""
+
+    def __init__(self, input_channels, hidden_channels, output_channels, num_layers, metadata, dropout=0.5,
+                 use_jk=False, fast=False, aggr="sum", **kwargs):
+        super().__init__()
+        self.metadata = (list(metadata[0]), [tuple(e) for e in metadata[1]])
+        self.num_layers = num_layers
+        self.fast = fast               # graphmuse's grouped-GEMM switch; this path is always fused
+        self.gnn = HeteroSAGEStack(self.metadata[1], input_channels, hidden_channels, num_layers, dropout, aggr)
+        self.use_jk = bool(use_jk)
+        if self.use_jk:
+            self.jk = JumpingKnowledge(hidden_channels, num_layers)
+        self.mlp = nn.Sequential(nn.Linear(hidden_channels, hidden_channels), nn.ReLU(),
+                                 nn.LayerNorm(hidden_channels), nn.Dropout(dropout),
+                                 nn.Linear(hidden_channels, output_channels))
+
+    def forward(self, x_dict, edge_index_dict, neighbor_mask_node=None, neighbor_mask_edge=None, batch_dict=None,
+                batch_size=None, return_edge_index=False, edge_attr_dict=None):
+        _lib.require_gpu(*x_dict.values())
+        plan = TrimPlan(self.num_layers, x_dict, edge_index_dict, neighbor_mask_node, neighbor_mask_edge)
+        outs: list = []
+        h = self.gnn(x_dict, edge_index_dict, plan, outs)["note"]
+        if batch_size is not None:
+            h = h[:batch_size]
+            outs = [o[:batch_size] for o in outs]
+        if self.use_jk:
+            h = self.jk(outs)
+        out = self.mlp(h)
+        return (out, edge_index_dict) if return_edge_index else out

@@ -1,0 +1,94 @@
+"""`TorchAnalysisGNN`: the caller-side boundary of the hot path, mirroring
+analysisgnn/models/analysis.py:421-591 (same constructor arguments, parameter names and
+`encode` / `forward_clf` / `forward` signatures) with the encoder and the onset pooling running
+on the HIP kernels.  Lightning training policy (losses, continual learning, schedulers) is out
+of scope."""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from .encoders import HybridGNN, MetricalGNN
+from .graph import SegSpec, build_csr
+
+
+def onset_pool(x: torch.Tensor, onset_edges: torch.Tensor, batch_size: int) -> torch.Tensor:
+    """analysis.py:580-587: onset edges with both ends < batch_size, self loops removed,
+    x_pool_i = (x_i + sum_j x_j) / max(cnt_i, 1), returned as cat([x, x_pool]).
+    The two boolean-mask compactions become kernel-side predicates (col < limit, col != row)."""
+    _lib.require_gpu(x, onset_edges)
+    n = int(x.shape[0])
+    fwd, bwd = build_csr([SegSpec(onset_edges[0], onset_edges[1], n_rows=max(n, batch_size)),
+                          SegSpec(onset_edges[1], onset_edges[0], n_rows=max(n, batch_size))])
+    spec = ops.AggSpec(fwd=[fwd], bwd=[bwd], src_id=[0], n_rows=min(n, batch_size), mean=True, shared_slot=True,
+                       skip_self=True, col_limit=batch_size)
+    pooled = ops.aggregate(spec, [x], self_t=x)
+    if pooled.shape[0] < n:                     # rows beyond batch_size keep their own value
+        pooled = torch.cat([pooled, x[pooled.shape[0]:]], dim=0)
+    return torch.cat([x, pooled], dim=-1)
+
+
+def _input_mlp(i, h, dropout):
+    return nn.Sequential(nn.Linear(i, h), nn.ReLU(), nn.LayerNorm(h), nn.Dropout(dropout), nn.Linear(h, h))
+
+
+class TorchAnalysisGNN(nn.Module):
+    def __init__(self, metadata, in_channels, hidden_channels, out_channels, task_dict, num_layers, dropout=0.5,
+                 use_jk=True, logit_fusion=False, use_rnn=False, encoder_type="hybridgnn"):
+        super().__init__()
+        if logit_fusion or use_rnn:
+            raise NotImplementedError("logit_fusion / use_rnn are outside the hot-path scope (SURVEY.md §8f)")
+        self.pitch_embedding = nn.Embedding(35, 64)
+        self.key_embedding = nn.Embedding(15, 64)
+        self.logit_fusion = logit_fusion
+        self.use_rnn = use_rnn
+        self.hidden_channels = hidden_channels
+        self.project_dict = nn.ModuleDict({
+            k: _input_mlp(in_channels + (128 if k == "note" else 0), hidden_channels, dropout) for k in metadata[0]})
+        if encoder_type == "hgt":
+            from .hgt import HybridHGT
+            self.encoder = HybridHGT(metadata=metadata, input_channels=hidden_channels, hidden_channels=hidden_channels,
+                                     num_layers=num_layers, heads=4, dropout=dropout, use_jk=use_jk)
+        elif encoder_type == "hybridgnn":
+            self.encoder = HybridGNN(metadata=metadata, input_channels=hidden_channels, hidden_channels=hidden_channels,
+                                     num_layers=num_layers, dropout=dropout, use_jk=use_jk)
+        elif encoder_type == "metricalgnn":
+            self.encoder = MetricalGNN(metadata=metadata, input_channels=hidden_channels, hidden_channels=hidden_channels,
+                                       output_channels=hidden_channels, num_layers=num_layers, dropout=dropout,
+                                       use_jk=use_jk, fast=True)
+        else:
+            raise ValueError(encoder_type)
+        h, o = hidden_channels, out_channels
+        self.project_enc = nn.Sequential(
+            nn.LayerNorm(2 * h), nn.Linear(2 * h, h), nn.ReLU(), nn.LayerNorm(h), nn.Dropout(dropout),
+            nn.Linear(h, o), nn.ReLU(), nn.LayerNorm(o), nn.Dropout(dropout), nn.Linear(o, o))
+        self.clf_dict = nn.ModuleDict({
+            t: nn.Sequential(nn.Linear(o, o // 2), nn.ReLU(), nn.LayerNorm(o // 2), nn.Linear(o // 2, c))
+            for t, c in task_dict.items()})
+
+    def encode(self, pitch_spelling, key_signature, x_dict, edge_index_dict, batch_dict, batch_size,
+               neighbor_mask_node, neighbor_mask_edge):
+        z_dict = dict(x_dict)
+        z_dict["note"] = torch.cat([z_dict["note"], self.pitch_embedding(pitch_spelling),
+                                    self.key_embedding(key_signature)], dim=-1)
+        h_dict = {k: self.project_dict[k](z_dict[k]) for k in self.project_dict.keys()}
+        x = self.encoder(x_dict=h_dict, edge_index_dict=edge_index_dict, batch_dict=batch_dict,
+                         batch_size=batch_size, neighbor_mask_node=neighbor_mask_node,
+                         neighbor_mask_edge=neighbor_mask_edge, return_edge_index=False, edge_attr_dict=None)
+        x = onset_pool(x, edge_index_dict[("note", "onset", "note")], batch_size)
+        return self.project_enc(x)
+
+    def forward_clf(self, x, tasks=None):
+        tasks = self.clf_dict.keys() if tasks is None else tasks
+        return {t: self.clf_dict[t](x) for t in tasks}
+
+    def forward(self, pitch_spelling, key_signature, x_dict, edge_index_dict, batch_dict, batch_size,
+                neighbor_mask_node, neighbor_mask_edge):
+        return self.forward_clf(self.encode(pitch_spelling, key_signature, x_dict, edge_index_dict, batch_dict,
+                                            batch_size, neighbor_mask_node, neighbor_mask_edge))
+
+    def clf_task(self, x, task_name):
+        return self.clf_dict[task_name](x)

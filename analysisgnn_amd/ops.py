@@ -40,15 +40,29 @@ def _view_ok(t: torch.Tensor) -> bool:
             and t.data_ptr() % 16 == 0)
 
 
+# When set to a list, every SpMM launch is bracketed by HIP events on the launch stream and
+# (tag, start_event, end_event, n_rel, n_rows, H, rel_stride) is appended — bench.py's live kernel timing.
+SPMM_TRACE: Optional[list] = None
+
+
 def _launch(rels: Sequence[dict], n_rows: int, H: int, out: torch.Tensor, rel_stride: int,
-            self_t: Optional[torch.Tensor], inv_cnt: Optional[torch.Tensor], col_limit: int, flags: int):
+            self_t: Optional[torch.Tensor], inv_cnt: Optional[torch.Tensor], col_limit: int, flags: int,
+            tag: str = "spmm"):
     lib = _lib.load()
     dev = out.device
     arr = _lib.make_rels(rels)
+    trace = SPMM_TRACE
+    if trace is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(dev))
     rc = lib.agnn_spmm_f32(len(rels), arr, n_rows, H, out.data_ptr(), out.stride(0), rel_stride,
                            _lib.ptr(self_t), self_t.stride(0) if self_t is not None else 0,
                            _lib.ptr(inv_cnt), min(int(col_limit), _lib.INT32_MAX), flags,
                            _lib.stream_ptr(dev))
+    if trace is not None:
+        e1.record(torch.cuda.current_stream(dev))
+        trace.append((tag, e0, e1, len(rels), n_rows, H, rel_stride))
     _lib.check(rc, "agnn_spmm_f32")
 
 
@@ -98,7 +112,7 @@ class _Aggregate(torch.autograd.Function):
                              col=csr.col.data_ptr(), ew=_lib.ptr(ew), ld_src=src.stride(0)))
         flags = (_lib.SPMM_MEAN if spec.mean else 0) | (_lib.SPMM_SKIP_SELF if spec.skip_self else 0)
         if n > 0:
-            _launch(rels, n, H, out, 0 if spec.shared_slot else H, self_c, inv_cnt, spec.col_limit, flags)
+            _launch(rels, n, H, out, 0 if spec.shared_slot else H, self_c, inv_cnt, spec.col_limit, flags, tag="fwd")
         ctx.spec = spec
         ctx.H = H
         ctx.src_rows = [s.shape[0] for s in srcs]
@@ -147,7 +161,7 @@ class _Aggregate(torch.autograd.Function):
                 g.zero_()
             else:
                 flags = _lib.SPMM_SKIP_SELF if spec.skip_self else 0
-                _launch(rels, rows_t, H, g, 0, None, None, n, flags)
+                _launch(rels, rows_t, H, g, 0, None, None, n, flags, tag="bwd")
             grads.append(g)
         gself = None
         if ctx.has_self and ctx.needs_input_grad[1]:

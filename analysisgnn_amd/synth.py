@@ -185,7 +185,8 @@ def make_batch(n_graphs: int, n_notes: int = 500, first_seed: int = 0, **kw) -> 
     return collate([make_score_graph(seed=first_seed + i, n_notes=n_notes, **kw) for i in range(n_graphs)])
 
 
-def sample_hops(g: ScoreGraph, n_targets: int, num_neighbors: Sequence[int], seed: int = 0) -> ScoreGraph:
+def sample_hops(g: ScoreGraph, n_targets: int, num_neighbors: Sequence[int], seed: int = 0,
+                random_targets: bool = False) -> ScoreGraph:
     """Neighbour-sampled view of a single note-only graph in PyG NeighborLoader layout.
 
     Targets are the first ``n_targets`` notes (a window, as MuseNeighborLoader takes —
@@ -197,7 +198,8 @@ def sample_hops(g: ScoreGraph, n_targets: int, num_neighbors: Sequence[int], see
     assert set(g.num_nodes) == {"note"}, "sample_hops handles note-only graphs"
     rng = np.random.default_rng(seed)
     n = g.num_nodes["note"]
-    order = list(range(n_targets))
+    order = (sorted(rng.choice(n, size=n_targets, replace=False).tolist()) if random_targets
+             else list(range(n_targets)))
     pos = {v: i for i, v in enumerate(order)}
     nodes_per_hop = [n_targets]
     in_lists = {}
@@ -208,7 +210,7 @@ def sample_hops(g: ScoreGraph, n_targets: int, num_neighbors: Sequence[int], see
         in_lists[et] = lst
     new_edges = {et: [] for et in g.edge_index}
     edges_per_hop = {et: [] for et in g.edge_index}
-    frontier = list(range(n_targets))
+    frontier = list(order)
     for fan in num_neighbors:
         nxt: List[int] = []
         for et in g.edge_index:
@@ -239,3 +241,23 @@ def sample_hops(g: ScoreGraph, n_targets: int, num_neighbors: Sequence[int], see
     out.extras["orig_id"] = order_arr
     assert n >= order_arr.size
     return out
+
+
+def torch_inputs(g: ScoreGraph, in_channels: int = 25, device="cpu", seed: int = 0):
+    """Tensors in the HeteroData layout `TorchAnalysisGNN.encode` consumes:
+    x_dict ~ N(0,1) float32, int64 COO edge_index_dict, batch_dict, pitch_spelling ~ U{0..34},
+    key_signature ~ U{0..14}, batch_size and the PyG per-hop count dicts (or None)."""
+    import torch
+    gen = torch.Generator().manual_seed(seed)
+    x_dict = {t: torch.randn(n, in_channels, generator=gen).to(device) for t, n in g.num_nodes.items()}
+    n_note = g.num_nodes["note"]
+    return dict(
+        x_dict=x_dict,
+        edge_index_dict={et: torch.from_numpy(np.ascontiguousarray(e)).to(device) for et, e in g.edge_index.items()},
+        batch_dict={t: torch.from_numpy(b).to(device) for t, b in g.batch.items()},
+        pitch_spelling=torch.randint(0, 35, (n_note,), generator=gen).to(device),
+        key_signature=torch.randint(0, 15, (n_note,), generator=gen).to(device),
+        batch_size=int(g.batch_size if g.batch_size is not None else n_note),
+        neighbor_mask_node=g.num_sampled_nodes,
+        neighbor_mask_edge=g.num_sampled_edges,
+    )

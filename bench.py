@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py — subgraph-nodes/sec, forward+backward, HybridGNN L=3 H=256 (BASELINE.json).
+
+One "step" = one training pass of the hot path over one batch of synthetic input already
+resident in HBM: TorchAnalysisGNN(encoder=HybridGNN, L=3, H=256, out=128, 21 task heads,
+dropout 0.3, use_jk off — the analysisgnn-train CLI defaults, train/train_analysisgnn.py:52-70)
+forward, label-smoothed multi-task CE + feature loss, backward, gradient all-reduce (N>1),
+gradient clipping (1.0) and AdamW step.  The COO->CSR index is rebuilt every step (a fresh
+sampled batch arrives every step in the reference's loader).  Workload C2: 32 subgraphs x 500
+notes per GPU (weak scaling: per-GPU work fixed).
+
+Launch:  python bench.py [--gpus N --steps K --warmup W]     (N>1 via torch.distributed.run)
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (hetero-SpMM
+aggregation kernel, HBM bound, live HIP-event timing) and `cpu_baseline` (oracle port on host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+TASK_DICT = {  # train/train_analysisgnn.py:22-45 (duplicate key "organ_point" collapses, as in the reference)
+    "cadence": 4, "localkey": 50, "tonkey": 50, "quality": 15, "inversion": 4, "root": 38, "bass": 38,
+    "degree1": 22, "degree2": 22, "hrythm": 2, "pcset": 94, "romanNumeral": 185, "section": 2, "phrase": 2,
+    "organ_point": 2, "tpc_in_label": 2, "tpc_is_root": 2, "tpc_is_bass": 2, "downbeat": 45, "note_degree": 49,
+    "staff": 4,
+}
+HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
+N_SUB, N_NOTES, IN_CH, H, OUT, LAYERS = 32, 500, 25, 256, 128, 3
+
+
+def make_labels(n, device, seed):
+    g = torch.Generator().manual_seed(seed)
+    return {t: torch.randint(0, c, (n,), generator=g).to(device) for t, c in TASK_DICT.items()}
+
+
+def loss_fn(logits, labels, feat):
+    import torch.nn.functional as F
+    loss = 0.1 * feat.pow(2).mean()                                   # analysis.py:984, lambda_featl=0.1
+    for t, y in labels.items():
+        loss = loss + F.cross_entropy(logits[t], y, ignore_index=-1, label_smoothing=0.1)   # analysis.py:881-888
+    return loss
+
+
+def spmm_alg_bytes(graph, n_rel_expected):
+    """B_alg = sum_r [4(N_dst+1) + 4 E_r] + 4H (N_src_unique + R N_dst), forward aggregation."""
+    ets = [et for et in graph.edge_index if et[2] == "note"]
+    assert len(ets) == n_rel_expected
+    n = graph.num_nodes["note"]
+    idx = sum(4 * (n + 1) + 4 * graph.edge_index[et].shape[1] for et in ets)
+    return idx + 4 * H * (n + len(ets) * n), sum(graph.edge_index[et].shape[1] for et in ets)
+
+
+def cpu_baseline(n_sub=8, iters=5):
+    """Oracle port (oracle/encoders_ref.py, pure PyTorch CPU) of the same model on a bounded sample."""
+    from analysisgnn_amd.models import TorchAnalysisGNN
+    from analysisgnn_amd.synth import make_batch, torch_inputs
+    from oracle import encoders_ref as E, rnn_ref
+    rnn_ref.USE_FAST = True
+    g = make_batch(n_sub, N_NOTES)
+    torch.manual_seed(0)
+    m = TorchAnalysisGNN(g.metadata(), IN_CH, H, OUT, TASK_DICT, LAYERS, dropout=0.3, use_jk=False,
+                         encoder_type="hybridgnn")
+    P = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    I = torch_inputs(g, IN_CH, "cpu", 0)
+    labels = make_labels(I["batch_size"], "cpu", 1)
+    cores = torch.get_num_threads()
+
+    def step():
+        for p in P.values():
+            p.grad = None
+        x = E.analysis_encode(P, "hybridgnn", g.metadata(), LAYERS, I["pitch_spelling"], I["key_signature"],
+                              I["x_dict"], I["edge_index_dict"], I["batch_dict"], I["batch_size"])
+        loss = loss_fn(E.analysis_logits(P, x, list(TASK_DICT)), labels, x)
+        loss.backward()
+    step()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": I["batch_size"] / dt, "unit": "subgraph-nodes/s", "cores": cores, "kind": "port",
+            "sample": f"{n_sub} subgraphs x {N_NOTES} notes, fwd+bwd (no optimizer), eval-mode oracle, "
+                      f"{iters} iters after 1 warm-up, {dt*1e3:.1f} ms/iter"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from analysisgnn_amd import dp, graph, ops
+    from analysisgnn_amd.models import TorchAnalysisGNN
+    from analysisgnn_amd.synth import make_batch, torch_inputs
+
+    rank, local, world = dp.init_distributed()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    # rank r owns subgraphs {r*32 .. r*32+31}: independent units, no data-path collective
+    g = make_batch(N_SUB, N_NOTES, first_seed=rank * N_SUB)
+    I = torch_inputs(g, IN_CH, dev, seed=rank)
+    labels = make_labels(I["batch_size"], dev, 100 + rank)
+    torch.manual_seed(0)                                            # identical replicas
+    model = TorchAnalysisGNN(g.metadata(), IN_CH, H, OUT, TASK_DICT, LAYERS, dropout=0.3, use_jk=False,
+                             encoder_type="hybridgnn").to(dev).train()
+    flat = dp.FlatGradBuffer(model.parameters())
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-3, weight_decay=5e-3, foreach=True)
+    graph.index_cache_enabled = False                               # fresh batch every step: rebuild the CSR
+
+    def step():
+        flat.zero()
+        x = model.encode(I["pitch_spelling"], I["key_signature"], I["x_dict"], I["edge_index_dict"], I["batch_dict"],
+                         I["batch_size"], None, None)
+        loss = loss_fn(model.forward_clf(x), labels, x)
+        loss.backward()
+        flat.all_reduce_mean()
+        flat.clip_norm_(1.0)
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    dp.barrier_and_sync()
+    ops.SPMM_TRACE = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    dp.barrier_and_sync()
+    dt = time.perf_counter() - t0
+    trace, ops.SPMM_TRACE = ops.SPMM_TRACE, None
+    dt = dp.max_over_ranks(dt)
+    assert torch.isfinite(loss).item(), "loss diverged"
+
+    if rank == 0:
+        nodes = I["batch_size"] * world * args.steps
+        # live timing of the dominant aggregation kernel: forward hetero SpMM, 4 relations -> [N, 4H]
+        fwd = [e0.elapsed_time(e1) * 1e-3 for (tag, e0, e1, nrel, nrows, h, rs) in trace if tag == "fwd" and nrel == 4]
+        bwd = [e0.elapsed_time(e1) * 1e-3 for (tag, e0, e1, nrel, nrows, h, rs) in trace if tag == "bwd" and nrel == 4]
+        b_alg, e_tot = spmm_alg_bytes(g, 4)
+        t_fwd = sum(fwd) / max(len(fwd), 1)
+        out = {
+            "metric": "subgraph-nodes/sec fwd+bwd, HybridGNN L=3 H=256", "value": nodes / dt,
+            "unit": "subgraph-nodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2: HybridGNN L=3 H=256 out=128, 21 task heads, 32 subgraphs x 500 notes per GPU "
+                                   "(4 note-note relations, 105,760 edges), train step fwd+loss+bwd+allreduce+clip+AdamW, "
+                                   "CSR rebuilt every step", "per_gpu_subgraphs": N_SUB, "notes_per_subgraph": N_NOTES,
+                       "parallelism": f"dp{world}"},
+            "roofline": {"bound": "hbm", "kernel": "k_spmm<1> forward hetero-SpMM (R=4, N=16000, H=256 -> [N,4H])",
+                         "achieved": b_alg / t_fwd / 1e9 if t_fwd > 0 else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": (b_alg / t_fwd) / HBM_PEAK if t_fwd > 0 else None, "traffic": None,
+                         "alg_bytes_per_launch": b_alg, "avg_us": t_fwd * 1e6, "launches": len(fwd),
+                         "bwd_avg_us": (sum(bwd) / max(len(bwd), 1)) * 1e6},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -90,3 +90,33 @@ def lstm(P: Mapping[str, torch.Tensor], prefix: str, x, num_layers: int = 1, bid
                 _get(P, f"{prefix}bias_ih_{k}"), _get(P, f"{prefix}bias_hh_{k}"), reverse=(d == 1)))
         y = torch.cat(outs, dim=-1)
     return y
+
+
+# ------------------------------------------------------------------------------------------
+# Fast path for TIMING the CPU baseline only: the same GRU through torch's native CPU kernel
+# (what `torch.nn.GRU` — the reference's own call, models/cadence.py:249-251 — executes).
+# tests/test_oracle_rnn.py checks it equals the explicit recurrence above.
+# ------------------------------------------------------------------------------------------
+USE_FAST = False
+
+
+def gru_fast(P: Mapping[str, torch.Tensor], prefix: str, x, num_layers: int = 1, bidirectional: bool = True):
+    flat = []
+    for layer in range(num_layers):
+        for suf in ["", "_reverse"][: 2 if bidirectional else 1]:
+            k = f"l{layer}{suf}"
+            flat += [P[f"{prefix}weight_ih_{k}"], P[f"{prefix}weight_hh_{k}"],
+                     P[f"{prefix}bias_ih_{k}"], P[f"{prefix}bias_hh_{k}"]]
+    H = flat[1].shape[1]
+    h0 = x.new_zeros(num_layers * (2 if bidirectional else 1), x.shape[0], H)
+    out, _ = torch._VF.gru(x, h0, flat, True, num_layers, 0.0, False, bidirectional, True)
+    return out
+
+
+_gru_loops = gru
+
+
+def gru(P, prefix, x, num_layers: int = 1, bidirectional: bool = True):  # noqa: F811
+    if USE_FAST and (prefix + "bias_ih_l0") in P:
+        return gru_fast(P, prefix, x, num_layers, bidirectional)
+    return _gru_loops(P, prefix, x, num_layers, bidirectional)

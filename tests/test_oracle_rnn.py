@@ -22,3 +22,13 @@ def test_lstm_matches_torch():
     ref, _ = m(x)
     got = rnn_ref.lstm(dict(m.state_dict()), "", x, num_layers=1, bidirectional=True)
     assert torch.allclose(got, ref, atol=1e-6)
+
+
+def test_fast_gru_equals_loops():
+    torch.manual_seed(1)
+    m = torch.nn.GRU(6, 4, num_layers=2, batch_first=True, bidirectional=True)
+    x = torch.randn(2, 9, 6)
+    P = dict(m.state_dict())
+    a = rnn_ref._gru_loops(P, "", x, 2, True)
+    b = rnn_ref.gru_fast(P, "", x, 2, True)
+    assert torch.allclose(a, b, atol=1e-6)
