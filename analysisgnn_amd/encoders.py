@@ -44,13 +44,18 @@ def et_key(et: EdgeType) -> str:
 # neighbour-mask conventions: per-hop counts, per-element hop index, or None
 # ------------------------------------------------------------------------------------------
 def _hop_counts(mask, keys, num_layers):
+    """Per-hop count lists.  Hop-index tensors (0 = target) are converted with one bincount per key;
+    all keys share one list length (deepest hop seen + 1) so that PyG's `[-layer]` indexing lines up."""
     out = {}
+    tens = {k: mask[k] for k in keys if k in mask and isinstance(mask[k], torch.Tensor)}
+    if tens:
+        depth = 1 + max((int(m.max()) if m.numel() else 0) for m in tens.values())   # host sync, once per batch
     for k in keys:
         if k not in mask:
             continue
         m = mask[k]
         if isinstance(m, torch.Tensor):
-            out[k] = torch.bincount(m, minlength=num_layers + 1).tolist()      # one host sync per batch
+            out[k] = torch.bincount(m, minlength=depth).tolist()
         else:
             out[k] = [int(v) for v in m]
     return out

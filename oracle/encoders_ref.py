@@ -44,13 +44,17 @@ def hop_counts(mask_node, mask_edge, x_dict, ei_dict, num_layers):
     if mask_node is None or mask_edge is None:
         return None, None
 
-    def conv(m, size):
+    def depth(masks):
+        t = [m for m in masks.values() if isinstance(m, torch.Tensor)]
+        return 1 + max((int(m.max()) if m.numel() else 0) for m in t) if t else 0
+    dn, de = depth(mask_node), depth(mask_edge)
+
+    def conv(m, d):
         if isinstance(m, torch.Tensor):
-            c = torch.bincount(m, minlength=num_layers + 1).tolist()
-            return c
+            return torch.bincount(m, minlength=d).tolist()
         return list(m)
-    nodes = {k: conv(mask_node[k], x_dict[k].shape[0]) for k in x_dict if k in mask_node}
-    edges = {k: conv(mask_edge[k], ei_dict[k].shape[1]) for k in ei_dict if k in mask_edge}
+    nodes = {k: conv(mask_node[k], dn) for k in x_dict if k in mask_node}
+    edges = {k: conv(mask_edge[k], de) for k in ei_dict if k in mask_edge}
     return nodes, edges
 
 

@@ -49,8 +49,8 @@ def test_hybrid_gnn(kind, aggr):
     g = _graph(kind)
     H, L = 32, 3
     torch.manual_seed(0)
-    m = HybridGNN(metadata=g.metadata(), input_channels=H, hidden_channels=H, num_layers=L, dropout=0.3,
-                  use_jk=(kind == "notes"), aggr=aggr).eval()
+    m = HybridGNN(metadata=g.metadata(), input_channels=H, hidden_channels=H, num_layers=L, dropout=0.0,
+                  use_jk=(kind == "notes"), aggr=aggr).train()
     P = _cpu_params(m)
     m = m.to(DEV)
     I = torch_inputs(g, in_channels=H, seed=1)
@@ -103,7 +103,7 @@ def test_analysis_model_logits(enc):
     H, L = 32, 3
     torch.manual_seed(2)
     m = TorchAnalysisGNN(g.metadata(), in_channels=25, hidden_channels=H, out_channels=16, task_dict=tasks,
-                         num_layers=L, dropout=0.3, use_jk=False, encoder_type=enc).eval()
+                         num_layers=L, dropout=0.0, use_jk=False, encoder_type=enc).train()
     P = _cpu_params(m)
     m = m.to(DEV)
     I = torch_inputs(g, in_channels=25, seed=3)
