@@ -1,0 +1,247 @@
+// Persistent bidirectional GRU layer for the hybrid (sequence) branch — gfx950.
+//
+// The reference runs `nn.GRU(H, H/2, num_layers=2, bidirectional=True)` over each subgraph's
+// padded target-note sequence (analysisgnn/models/cadence.py:249-285, models/analysis.py:527-537).
+// The library RNN path launches several tiny kernels per time step (T = 500 steps x 2 layers):
+// ~24 000 launches per training step, >90 % of the step.  Here one 512-thread workgroup owns one
+// (sequence, direction) chain for ALL T steps: W_hh (3*HH x HH fp32 = 192 KiB at HH = 128) lives in
+// registers (96 per thread), h_{t-1} in LDS (double-buffered, one barrier per step), the
+// recurrent mat-vec is 96 FMAs per thread + a 3-step DPP butterfly over the 8 lanes that share
+// an output row.  The input projection x W_ih^T (+b_ih) is a plain library GEMM done beforehand
+// for all steps at once.  The backward kernel walks the chain in reverse with W_hh^T in
+// registers and emits dGI / dHN; weight gradients are library GEMMs over those.
+// Exact fp32 (expf-based sigmoid/tanh), no atomics, bitwise reproducible.
+#include "agnn_common.h"
+
+namespace {
+
+constexpr int HH = 128;        // hidden size per direction
+constexpr int NT = 512;        // threads per chain: 64 unit-pairs x 8 k-chunks
+constexpr int KC = 8;
+
+__device__ __forceinline__ float dpp_xor1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float dpp_xor2(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+}
+__device__ __forceinline__ float dpp_half_mirror(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false)); // lane i <-> 7-i in each 8
+}
+// sum over the 8 consecutive lanes of a unit-pair group; every lane ends with the total
+__device__ __forceinline__ float group8_sum(float v) {
+  v += dpp_xor1(v);
+  v += dpp_xor2(v);
+  v += dpp_half_mirror(v);
+  return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 2.f / (1.f + expf(-2.f * x)) - 1.f; }
+
+// gi   [B, T, 2, 3*HH]  x W_ih^T + b_ih, gate order r,z,n (torch)
+// w_hh [2, 3*HH, HH], b_hh [2, 3*HH]
+// y    [B, T, 2*HH]
+// saved[B, T, 2, 4, HH]  = r, z, n, (W_hn h + b_hn)
+__global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, const float* __restrict__ w_hh,
+                                                const float* __restrict__ b_hh, int T, float* __restrict__ y,
+                                                float* __restrict__ saved) {
+  __shared__ __attribute__((aligned(16))) float hbuf[2][HH];
+  const int b = blockIdx.x >> 1, d = blockIdx.x & 1;
+  const int tid = threadIdx.x, g = tid >> 3, kc = tid & 7;
+  const int u0 = 2 * g;
+  const float* W = w_hh + static_cast<size_t>(d) * 3 * HH * HH;
+  float w[3][2][16];
+#pragma unroll
+  for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float4* src = reinterpret_cast<const float4*>(W + static_cast<size_t>(gate * HH + u0 + q) * HH + 16 * kc);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float4 t4 = src[v];
+        w[gate][q][4 * v + 0] = t4.x; w[gate][q][4 * v + 1] = t4.y;
+        w[gate][q][4 * v + 2] = t4.z; w[gate][q][4 * v + 3] = t4.w;
+      }
+    }
+  float bh[3][2];
+#pragma unroll
+  for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) bh[gate][q] = b_hh[d * 3 * HH + gate * HH + u0 + q];
+  if (tid < HH) { hbuf[0][tid] = 0.f; hbuf[1][tid] = 0.f; }
+  float hprev[2] = {0.f, 0.f};
+  __syncthreads();
+
+  const size_t row3 = static_cast<size_t>(2) * 3 * HH;
+  auto gi_ptr = [&](int t) { return gi + (static_cast<size_t>(b) * T + t) * row3 + static_cast<size_t>(d) * 3 * HH + u0; };
+  int t = d ? T - 1 : 0;
+  float gin[3][2];
+  {
+    const float* p = gi_ptr(t);
+#pragma unroll
+    for (int gate = 0; gate < 3; ++gate) {
+      const float2 v = *reinterpret_cast<const float2*>(p + gate * HH);
+      gin[gate][0] = v.x; gin[gate][1] = v.y;
+    }
+  }
+  for (int s = 0; s < T; ++s) {
+    const int cur = s & 1;
+    const int tn = d ? t - 1 : t + 1;
+    float gnext[3][2];
+    if (s + 1 < T) {                       // prefetch next step's input projection
+      const float* p = gi_ptr(tn);
+#pragma unroll
+      for (int gate = 0; gate < 3; ++gate) {
+        const float2 v = *reinterpret_cast<const float2*>(p + gate * HH);
+        gnext[gate][0] = v.x; gnext[gate][1] = v.y;
+      }
+    } else {
+#pragma unroll
+      for (int gate = 0; gate < 3; ++gate) gnext[gate][0] = gnext[gate][1] = 0.f;
+    }
+    float hk[16];
+    {
+      const float4* hp = reinterpret_cast<const float4*>(&hbuf[cur][16 * kc]);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float4 t4 = hp[v];
+        hk[4 * v + 0] = t4.x; hk[4 * v + 1] = t4.y; hk[4 * v + 2] = t4.z; hk[4 * v + 3] = t4.w;
+      }
+    }
+    float gh[3][2];
+#pragma unroll
+    for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) {
+          a0 = fmaf(w[gate][q][k], hk[k], a0);
+          a1 = fmaf(w[gate][q][k + 1], hk[k + 1], a1);
+        }
+        gh[gate][q] = group8_sum(a0 + a1) + bh[gate][q];
+      }
+    float hnew[2], rr[2], zz[2], nn[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      rr[q] = sigmoidf_(gin[0][q] + gh[0][q]);
+      zz[q] = sigmoidf_(gin[1][q] + gh[1][q]);
+      nn[q] = tanhf_(gin[2][q] + rr[q] * gh[2][q]);
+      hnew[q] = (1.f - zz[q]) * nn[q] + zz[q] * hprev[q];
+      hprev[q] = hnew[q];
+    }
+    if (kc == 0) {
+      *reinterpret_cast<float2*>(&hbuf[cur ^ 1][u0]) = make_float2(hnew[0], hnew[1]);
+      const size_t bt = static_cast<size_t>(b) * T + t;
+      *reinterpret_cast<float2*>(y + bt * 2 * HH + d * HH + u0) = make_float2(hnew[0], hnew[1]);
+      float* sv = saved + (bt * 2 + d) * 4 * HH + u0;
+      *reinterpret_cast<float2*>(sv + 0 * HH) = make_float2(rr[0], rr[1]);
+      *reinterpret_cast<float2*>(sv + 1 * HH) = make_float2(zz[0], zz[1]);
+      *reinterpret_cast<float2*>(sv + 2 * HH) = make_float2(nn[0], nn[1]);
+      *reinterpret_cast<float2*>(sv + 3 * HH) = make_float2(gh[2][0], gh[2][1]);
+    }
+#pragma unroll
+    for (int gate = 0; gate < 3; ++gate) { gin[gate][0] = gnext[gate][0]; gin[gate][1] = gnext[gate][1]; }
+    t = tn;
+    __syncthreads();
+  }
+}
+
+// dy [B,T,2*HH]; y, saved from the forward; outputs dgi [B,T,2,3*HH] (d r_pre, d z_pre, d n_pre) and
+// dhn [B,T,2,HH] (gradient of W_hn h + b_hn).
+__global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, const float* __restrict__ y,
+                                                const float* __restrict__ saved, const float* __restrict__ w_hh,
+                                                int T, float* __restrict__ dgi, float* __restrict__ dhn_out) {
+  __shared__ __attribute__((aligned(16))) float dgh[2][3 * HH];
+  const int b = blockIdx.x >> 1, d = blockIdx.x & 1;
+  const int tid = threadIdx.x, g = tid >> 3, kc = tid & 7;
+  const int u0 = 2 * g;
+  const float* W = w_hh + static_cast<size_t>(d) * 3 * HH * HH;
+  constexpr int JC = 3 * HH / KC;   // 48 rows of W per lane chunk
+  float wt[2][JC];
+#pragma unroll
+  for (int j = 0; j < JC; ++j) {
+    const float2 v = *reinterpret_cast<const float2*>(W + static_cast<size_t>(JC * kc + j) * HH + u0);
+    wt[0][j] = v.x; wt[1][j] = v.y;
+  }
+  float carry[2] = {0.f, 0.f};
+  for (int s = 0; s < T; ++s) {
+    const int cur = s & 1;
+    const int t = d ? s : T - 1 - s;            // reverse of the forward walk
+    const int tp = d ? t + 1 : t - 1;           // forward predecessor of t in this direction
+    const size_t bt = static_cast<size_t>(b) * T + t;
+    const float2 dyv = *reinterpret_cast<const float2*>(dy + bt * 2 * HH + d * HH + u0);
+    const float* sv = saved + (bt * 2 + d) * 4 * HH + u0;
+    const float2 r2 = *reinterpret_cast<const float2*>(sv + 0 * HH);
+    const float2 z2 = *reinterpret_cast<const float2*>(sv + 1 * HH);
+    const float2 n2 = *reinterpret_cast<const float2*>(sv + 2 * HH);
+    const float2 q2 = *reinterpret_cast<const float2*>(sv + 3 * HH);
+    float2 hp2 = make_float2(0.f, 0.f);
+    if (tp >= 0 && tp < T) hp2 = *reinterpret_cast<const float2*>(y + (static_cast<size_t>(b) * T + tp) * 2 * HH + d * HH + u0);
+    const float dyq[2] = {dyv.x, dyv.y}, r[2] = {r2.x, r2.y}, z[2] = {z2.x, z2.y}, n[2] = {n2.x, n2.y},
+                hn[2] = {q2.x, q2.y}, hp[2] = {hp2.x, hp2.y};
+    float dh[2], drp[2], dzp[2], dnp[2], dq[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      dh[q] = dyq[q] + carry[q];
+      const float dn = dh[q] * (1.f - z[q]);
+      const float dz = dh[q] * (hp[q] - n[q]);
+      dnp[q] = dn * (1.f - n[q] * n[q]);
+      const float dr = dnp[q] * hn[q];
+      dq[q] = dnp[q] * r[q];
+      dzp[q] = dz * z[q] * (1.f - z[q]);
+      drp[q] = dr * r[q] * (1.f - r[q]);
+    }
+    if (kc == 0) {
+      float* go = dgi + (bt * 2 + d) * 3 * HH + u0;
+      *reinterpret_cast<float2*>(go + 0 * HH) = make_float2(drp[0], drp[1]);
+      *reinterpret_cast<float2*>(go + 1 * HH) = make_float2(dzp[0], dzp[1]);
+      *reinterpret_cast<float2*>(go + 2 * HH) = make_float2(dnp[0], dnp[1]);
+      *reinterpret_cast<float2*>(dhn_out + (bt * 2 + d) * HH + u0) = make_float2(dq[0], dq[1]);
+      *reinterpret_cast<float2*>(&dgh[cur][0 * HH + u0]) = make_float2(drp[0], drp[1]);
+      *reinterpret_cast<float2*>(&dgh[cur][1 * HH + u0]) = make_float2(dzp[0], dzp[1]);
+      *reinterpret_cast<float2*>(&dgh[cur][2 * HH + u0]) = make_float2(dq[0], dq[1]);
+    }
+    __syncthreads();
+    float a[2] = {0.f, 0.f}, c[2] = {0.f, 0.f};
+    const float4* gp = reinterpret_cast<const float4*>(&dgh[cur][JC * kc]);
+#pragma unroll
+    for (int v = 0; v < JC / 4; ++v) {
+      const float4 t4 = gp[v];
+      a[0] = fmaf(wt[0][4 * v + 0], t4.x, a[0]); a[1] = fmaf(wt[1][4 * v + 0], t4.x, a[1]);
+      c[0] = fmaf(wt[0][4 * v + 1], t4.y, c[0]); c[1] = fmaf(wt[1][4 * v + 1], t4.y, c[1]);
+      a[0] = fmaf(wt[0][4 * v + 2], t4.z, a[0]); a[1] = fmaf(wt[1][4 * v + 2], t4.z, a[1]);
+      c[0] = fmaf(wt[0][4 * v + 3], t4.w, c[0]); c[1] = fmaf(wt[1][4 * v + 3], t4.w, c[1]);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) carry[q] = dh[q] * z[q] + group8_sum(a[q] + c[q]);
+  }
+}
+
+}  // namespace
+
+extern "C" int agnn_gru_fwd_f32(const float* gi, const float* w_hh, const float* b_hh, int64_t B, int64_t T,
+                                int32_t hidden, float* y, float* saved, agnn_stream_t stream_) {
+  using namespace agnn;
+  if (hidden != HH) return fail(AGNN_EINVAL, "gru_fwd: hidden=%d unsupported (this build: %d)", hidden, HH);
+  if (B < 0 || T < 0 || B * 2 >= (int64_t{1} << 31) || T >= (int64_t{1} << 31)) return fail(AGNN_EINVAL, "gru_fwd: bad B=%lld T=%lld", (long long)B, (long long)T);
+  if (B == 0 || T == 0) return AGNN_OK;
+  if (!gi || !w_hh || !b_hh || !y || !saved) return fail(AGNN_EINVAL, "gru_fwd: null argument");
+  if (!aligned16(gi) || !aligned16(w_hh) || !aligned16(y) || !aligned16(saved)) return fail(AGNN_EALIGN, "gru_fwd: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(k_gru_fwd, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), gi,
+                     w_hh, b_hh, static_cast<int>(T), y, saved);
+  return check_launch("gru_fwd");
+}
+
+extern "C" int agnn_gru_bwd_f32(const float* dy, const float* y, const float* saved, const float* w_hh, int64_t B,
+                                int64_t T, int32_t hidden, float* dgi, float* dhn, agnn_stream_t stream_) {
+  using namespace agnn;
+  if (hidden != HH) return fail(AGNN_EINVAL, "gru_bwd: hidden=%d unsupported (this build: %d)", hidden, HH);
+  if (B < 0 || T < 0 || B * 2 >= (int64_t{1} << 31) || T >= (int64_t{1} << 31)) return fail(AGNN_EINVAL, "gru_bwd: bad B=%lld T=%lld", (long long)B, (long long)T);
+  if (B == 0 || T == 0) return AGNN_OK;
+  if (!dy || !y || !saved || !w_hh || !dgi || !dhn) return fail(AGNN_EINVAL, "gru_bwd: null argument");
+  if (!aligned16(dy) || !aligned16(y) || !aligned16(saved) || !aligned16(w_hh) || !aligned16(dgi) || !aligned16(dhn)) return fail(AGNN_EALIGN, "gru_bwd: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(k_gru_bwd, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), dy, y,
+                     saved, w_hh, static_cast<int>(T), dgi, dhn);
+  return check_launch("gru_bwd");
+}

@@ -30,6 +30,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib, ops
+from .gru import gru_forward
 from .core_layers import JumpingKnowledge
 from .graph import HeteroIndex, hetero_index
 
@@ -174,7 +175,7 @@ class HeteroSAGEStack(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------
-# hybrid (sequence) branch — MIOpen GRU for now
+# hybrid (sequence) branch — persistent GRU kernels (gru.py) for hidden 128, library RNN otherwise
 # ------------------------------------------------------------------------------------------
 class _HybridMixin:
     def _init_hybrid(self, input_channels, hidden_channels, num_layers, dropout, use_jk):
@@ -194,11 +195,11 @@ class _HybridMixin:
         lens = lengths.tolist()
         if len(set(lens)) == 1:                     # equal windows (the usual batch): a view, no padding
             y = x.view(len(lens), lens[0], x.shape[1])
-            y, _ = self.rnn(y)
+            y = gru_forward(self.rnn, y, self.training)
             y = self.rnn_mlp(self.rnn_norm(y))
             return y.reshape(-1, y.shape[-1])
         seqs = nn.utils.rnn.pad_sequence(x.split(lens), batch_first=True, padding_value=0.0)
-        y, _ = self.rnn(seqs)
+        y = gru_forward(self.rnn, seqs, self.training)
         y = self.rnn_mlp(self.rnn_norm(y))
         return torch.cat(nn.utils.rnn.unpad_sequence(y, batch_first=True, lengths=lengths.cpu()), dim=0)
 

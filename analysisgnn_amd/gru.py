@@ -1,0 +1,86 @@
+"""Host side of the persistent GRU kernels (include/agnn.h: agnn_gru_fwd_f32 / agnn_gru_bwd_f32).
+
+Takes the parameters of a plain `torch.nn.GRU(batch_first=True, bidirectional=True)` — the module
+the reference's hybrid branch builds (analysisgnn/models/cadence.py:249-251) — so `state_dict`s stay
+identical; the input projections and all weight gradients are library GEMMs, the T-step
+recurrence (forward and backward) is one kernel launch per layer."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+KERNEL_HIDDEN = 128
+
+
+class _GRULayer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+        # x [B,T,I]; w_ih [2,3H,I]; w_hh [2,3H,H]; b_ih, b_hh [2,3H]
+        dev = _lib.require_gpu(x, w_ih, w_hh, b_ih, b_hh)
+        B, T, I = x.shape
+        Hh = w_hh.shape[2]
+        x2 = x.reshape(B * T, I)
+        gi = torch.addmm(b_ih.reshape(1, -1), x2, w_ih.reshape(6 * Hh, I).t())      # [B*T, 2*3H]
+        w_hh_c = w_hh.contiguous()
+        b_hh_c = b_hh.contiguous()
+        y = torch.empty((B, T, 2 * Hh), dtype=torch.float32, device=dev)
+        saved = torch.empty((B, T, 2, 4, Hh), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        _lib.check(lib.agnn_gru_fwd_f32(gi.data_ptr(), w_hh_c.data_ptr(), b_hh_c.data_ptr(), B, T, Hh,
+                                        y.data_ptr(), saved.data_ptr(), _lib.stream_ptr(dev)), "agnn_gru_fwd_f32")
+        ctx.save_for_backward(x2, w_ih, w_hh_c, y, saved)
+        ctx.dims = (B, T, I, Hh)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w_ih, w_hh, y, saved = ctx.saved_tensors
+        B, T, I, Hh = ctx.dims
+        dev = dy.device
+        dy = dy.contiguous()
+        dgi = torch.empty((B, T, 2, 3 * Hh), dtype=torch.float32, device=dev)
+        dhn = torch.empty((B, T, 2, Hh), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        _lib.check(lib.agnn_gru_bwd_f32(dy.data_ptr(), y.data_ptr(), saved.data_ptr(), w_hh.data_ptr(), B, T, Hh,
+                                        dgi.data_ptr(), dhn.data_ptr(), _lib.stream_ptr(dev)), "agnn_gru_bwd_f32")
+        dgi2 = dgi.view(B * T, 6 * Hh)
+        wf = w_ih.reshape(6 * Hh, I)
+        dx = (dgi2 @ wf).view(B, T, I) if ctx.needs_input_grad[0] else None
+        dw_ih = (dgi2.t() @ x2).view(2, 3 * Hh, I)
+        db_ih = dgi2.sum(dim=0).view(2, 3 * Hh)
+        dgh = torch.cat([dgi[..., : 2 * Hh], dhn], dim=-1)                              # [B,T,2,3H]
+        hp = torch.zeros((B, T, 2, Hh), dtype=torch.float32, device=dev)                 # h_{t-1} per direction
+        if T > 1:
+            hp[:, 1:, 0] = y[:, :-1, :Hh]
+            hp[:, :-1, 1] = y[:, 1:, Hh:]
+        dw_hh = torch.einsum("btdj,btdk->djk", dgh, hp)
+        db_hh = dgh.sum(dim=(0, 1))
+        return dx, dw_ih, dw_hh, db_ih, db_hh
+
+
+def kernel_applicable(rnn: nn.GRU) -> bool:
+    return (isinstance(rnn, nn.GRU) and rnn.hidden_size == KERNEL_HIDDEN and rnn.bidirectional and rnn.batch_first
+            and rnn.bias and getattr(rnn, "proj_size", 0) == 0)
+
+
+def gru_forward(rnn: nn.GRU, x: torch.Tensor, training: bool) -> torch.Tensor:
+    """y = rnn(x)[0] with zero initial state.  Persistent HIP kernels when hidden_size == 128
+    (H = 256 models); any other size runs the library RNN (MIOpen) — still on the GPU."""
+    _lib.require_gpu(x)
+    if not kernel_applicable(rnn):
+        return rnn(x)[0]
+    y = x
+    for layer in range(rnn.num_layers):
+        def p(n, layer=layer):
+            return getattr(rnn, f"{n}_l{layer}"), getattr(rnn, f"{n}_l{layer}_reverse")
+        w_ih = torch.stack(p("weight_ih"))
+        w_hh = torch.stack(p("weight_hh"))
+        b_ih = torch.stack(p("bias_ih"))
+        b_hh = torch.stack(p("bias_hh"))
+        y = _GRULayer.apply(y.contiguous(), w_ih, w_hh, b_ih, b_hh)
+        if layer < rnn.num_layers - 1 and rnn.dropout > 0 and training:
+            y = F.dropout(y, rnn.dropout, True)
+    return y

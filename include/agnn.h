@@ -14,9 +14,7 @@
  *                         out=...)` (ref: core/gnn.py:70-74, :511, :539; core/hgnn.py:406-407;
  *                         models/analysis.py:580-586) and PyG `SAGEConv` mean aggregation under
  *                         `HeteroConv` (ref: models/cadence.py:147-159,174)
- *   agnn_hgt_attn_*       PyG `HGTConv` message/softmax/aggregate (reached through graphmuse
- *                         `HybridHGT`, ref: models/analysis.py:445-453)
- *   agnn_gated_spmm_*     `ResGatedGraphConv` edge gate + scatter (ref: core/gnn.py:246-257)
+ *   agnn_gru_fwd/bwd_f32  `torch.nn.GRU` of the hybrid sequence branch (ref: models/cadence.py:249-285)
  *
  * Conventions (all entry points)
  *   - plain pointers and sizes only; every `const T*`/`T*` marked (device) is device memory owned
@@ -119,6 +117,24 @@ int agnn_spmm_f32(int n_rel, const agnn_rel_t* rels /* (host) */, int64_t n_rows
                   float* out, int64_t ld_out, int64_t rel_stride,
                   const float* self, int64_t ld_self,
                   float* inv_cnt, int32_t col_limit, uint32_t flags, agnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Persistent bidirectional GRU layer (one launch for all T steps), replacing `torch.nn.GRU` in the
+ * hybrid branch (ref: models/cadence.py:249-285, models/analysis.py:527-537).  hidden must be 128
+ * (the H = 256 configuration); other sizes return AGNN_EINVAL and the host falls back to the
+ * library RNN.  Gate order r, z, n and equations are torch's.
+ *   gi    [B, T, 2, 3*hidden]   x W_ih^T + b_ih for both directions (library GEMM, done by the caller)
+ *   w_hh  [2, 3*hidden, hidden], b_hh [2, 3*hidden]
+ *   y     [B, T, 2*hidden]      forward | reverse halves, as nn.GRU(batch_first) returns
+ *   saved [B, T, 2, 4, hidden]  r, z, n, W_hn h + b_hn  (kept for the backward pass)
+ * Backward: given dy emits dgi [B, T, 2, 3*hidden] (gradient w.r.t. gi) and dhn [B, T, 2, hidden]
+ * (gradient w.r.t. W_hn h + b_hn); weight/input gradients are GEMMs over those.
+ * ------------------------------------------------------------------------------------------ */
+int agnn_gru_fwd_f32(const float* gi, const float* w_hh, const float* b_hh, int64_t B, int64_t T,
+                     int32_t hidden, float* y, float* saved, agnn_stream_t stream);
+int agnn_gru_bwd_f32(const float* dy, const float* y, const float* saved, const float* w_hh,
+                     int64_t B, int64_t T, int32_t hidden, float* dgi, float* dhn,
+                     agnn_stream_t stream);
 
 #ifdef __cplusplus
 }
