@@ -43,6 +43,7 @@ def _view_ok(t: torch.Tensor) -> bool:
 # When set to a list, every SpMM launch is bracketed by HIP events on the launch stream and
 # (tag, start_event, end_event, n_rel, n_rows, H, rel_stride) is appended — bench.py's live kernel timing.
 SPMM_TRACE: Optional[list] = None
+SPMM_VARIANT = 0           # tests / A-B timing: 1024 = AGNN_SPMM_GENERIC (never take the fast path)
 
 
 def _launch(rels: Sequence[dict], n_rows: int, H: int, out: torch.Tensor, rel_stride: int,
@@ -58,7 +59,7 @@ def _launch(rels: Sequence[dict], n_rows: int, H: int, out: torch.Tensor, rel_st
         e0.record(torch.cuda.current_stream(dev))
     rc = lib.agnn_spmm_f32(len(rels), arr, n_rows, H, out.data_ptr(), out.stride(0), rel_stride,
                            _lib.ptr(self_t), self_t.stride(0) if self_t is not None else 0,
-                           _lib.ptr(inv_cnt), min(int(col_limit), _lib.INT32_MAX), flags,
+                           _lib.ptr(inv_cnt), min(int(col_limit), _lib.INT32_MAX), flags | SPMM_VARIANT,
                            _lib.stream_ptr(dev))
     if trace is not None:
         e1.record(torch.cuda.current_stream(dev))
@@ -161,7 +162,9 @@ class _Aggregate(torch.autograd.Function):
                 g.zero_()
             else:
                 flags = _lib.SPMM_SKIP_SELF if spec.skip_self else 0
-                _launch(rels, rows_t, H, g, 0, None, None, n, flags, tag="bwd")
+                # only a trimmed forward (fewer output rows than the CSR has) needs the column filter
+                lim = n if any(c.n_rows > n for c in spec.fwd) else _lib.INT32_MAX
+                _launch(rels, rows_t, H, g, 0, None, None, lim, flags, tag="bwd")
             grads.append(g)
         gself = None
         if ctx.has_self and ctx.needs_input_grad[1]:
