@@ -30,6 +30,12 @@ class Rel(C.Structure):
                 ("ew", C.c_void_p), ("colscale", C.c_void_p), ("ld_src", C.c_int64)]
 
 
+class HgtRel(C.Structure):
+    _fields_ = [("k", C.c_void_p), ("v", C.c_void_p), ("rowptr", C.c_void_p), ("rowend", C.c_void_p),
+                ("col", C.c_void_p), ("perm", C.c_void_p), ("pscale", C.c_void_p), ("ld", C.c_int64),
+                ("alpha", C.c_void_p), ("gs", C.c_void_p), ("tdot", C.c_void_p)]
+
+
 _lib: Optional[C.CDLL] = None
 
 # every exported symbol of include/agnn.h: (name, restype, argtypes)
@@ -47,6 +53,14 @@ SIGNATURES = {
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "agnn_gru_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "agnn_hgt_attn_fwd_f32": (C.c_int, [C.c_int, C.POINTER(HgtRel), C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
+                                        C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "agnn_hgt_attn_bwd_dst_f32": (C.c_int, [C.c_int, C.POINTER(HgtRel), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                            C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                            C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "agnn_hgt_attn_bwd_src_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
+                                            C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
 }
 
 

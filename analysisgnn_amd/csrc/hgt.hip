@@ -1,0 +1,337 @@
+// HGT edge-softmax attention (PyG HGTConv message / softmax / aggregate) for gfx950.
+//
+// Reference path: graphmuse `HybridHGT` -> torch_geometric `HGTConv(heads=4)` reached from
+// analysisgnn/models/analysis.py:445-453 (no in-tree implementation).  Semantics restated in
+// SURVEY.md App. A.4 and oracle/pyg_ref.py::hgt_conv: for destination row i and head h
+//     s_e  = <q_i,h , k'_e,h> * p_rel[r(e),h] / sqrt(D)        over ALL incoming edges of all relations
+//     a_e  = exp(s_e - max) / (sum_e exp(s_e - max) + 1e-16)
+//     m_i,h = sum_e a_e v'_e,h
+// where k' = k A_r^k, v' = v A_r^v are the relation-transformed keys / values of the source node
+// (dense grouped GEMMs done by the caller).
+//
+// One wavefront per destination row, a lane owns 4 consecutive floats of every 256-float chunk,
+// so the D = H/heads floats of a head sit in D/4 adjacent lanes and the per-head dot products are
+// butterfly reductions inside those lane groups.  Single pass over the concatenated CSR segments
+// with an online (running max / running sum) softmax: K' and V' rows are read exactly once, the
+// [E, heads] score matrix is never materialised in the forward.  Backward = one pass by destination
+// (recomputes the probabilities from the saved max / 1/sum, emits dq and per-edge alpha, ds) and
+// one pass by source over the transposed CSR (dK', dV'): no atomics, bitwise reproducible.
+// HBM/L2-bound gather work; no MFMA here.
+#include <cmath>
+
+#include "agnn_common.h"
+
+namespace {
+
+struct HgtTable {
+  agnn_hgt_rel_t r[AGNN_MAX_SEG];
+  int n_rel;
+};
+
+__device__ __forceinline__ float4 f4z() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+  return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
+}
+// sum over the gl (power of two <= 64) adjacent lanes that hold one head; every lane gets the total
+__device__ __forceinline__ float group_sum(float v, int gl) {
+  for (int off = 1; off < gl; off <<= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+struct HgtArgs {
+  const float* q;
+  int64_t ld_q;
+  int32_t n_rows;
+  int32_t H;
+  int32_t heads;
+  int32_t col_limit;
+};
+
+template <int CH>
+__global__ __launch_bounds__(256) void k_hgt_fwd(HgtTable t, HgtArgs a, float* __restrict__ out, int64_t ld_out,
+                                                 float* __restrict__ m_out, float* __restrict__ linv_out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int vb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-contiguous row slabs
+  const int row = vb * 4 + wave;
+  if (row >= a.n_rows) return;
+  const int D = a.H / a.heads;
+  const int gl = D >> 2;
+  bool on[CH];
+  int head[CH];
+  float4 qv[CH], acc[CH];
+  float m[CH], l[CH];
+  const float4* qp = reinterpret_cast<const float4*>(a.q + static_cast<int64_t>(row) * a.ld_q);
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int f = c * 256 + lane * 4;
+    on[c] = f < a.H;
+    head[c] = on[c] ? f / D : 0;
+    qv[c] = on[c] ? qp[c * 64 + lane] : f4z();
+    acc[c] = f4z();
+    m[c] = -INFINITY;
+    l[c] = 0.f;
+  }
+  for (int r = 0; r < t.n_rel; ++r) {
+    const agnn_hgt_rel_t& R = t.r[r];
+    const int start = R.rowptr[row];
+    const int end = (R.rowend != nullptr) ? R.rowend[row] : R.rowptr[row + 1];
+    float ps[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) ps[c] = R.pscale[head[c]];
+    for (int p = start; p < end; ++p) {
+      const int j = __builtin_amdgcn_readfirstlane(R.col[p]);
+      const float4* kp = reinterpret_cast<const float4*>(R.k + static_cast<int64_t>(j) * R.ld);
+      const float4* vp = reinterpret_cast<const float4*>(R.v + static_cast<int64_t>(j) * R.ld);
+      float4 kv[CH], vv[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        kv[c] = on[c] ? kp[c * 64 + lane] : f4z();
+        vv[c] = on[c] ? vp[c * 64 + lane] : f4z();
+      }
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const float s = group_sum(dot4(qv[c], kv[c]), gl) * ps[c];
+        const float mn = fmaxf(m[c], s);
+        const float corr = expf(m[c] - mn);       // exp(-inf) = 0 on the first edge
+        const float pe = expf(s - mn);
+        l[c] = l[c] * corr + pe;
+        acc[c].x = acc[c].x * corr + pe * vv[c].x;
+        acc[c].y = acc[c].y * corr + pe * vv[c].y;
+        acc[c].z = acc[c].z * corr + pe * vv[c].z;
+        acc[c].w = acc[c].w * corr + pe * vv[c].w;
+        m[c] = mn;
+      }
+    }
+  }
+  float4* op = reinterpret_cast<float4*>(out + static_cast<int64_t>(row) * ld_out);
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    if (!on[c]) continue;
+    const float linv = 1.f / (l[c] + 1e-16f);
+    float4 o = acc[c];
+    o.x *= linv; o.y *= linv; o.z *= linv; o.w *= linv;
+    op[c * 64 + lane] = o;
+    if (((c * 256 + lane * 4) % D) == 0) {
+      m_out[static_cast<int64_t>(row) * a.heads + head[c]] = m[c];
+      linv_out[static_cast<int64_t>(row) * a.heads + head[c]] = linv;
+    }
+  }
+}
+
+// Pass by destination: dq, and per edge (indexed by the edge's COO position `perm`) alpha, gs = ds * pscale,
+// tdot = ds * <q,k'> (for the gradient of p_rel).
+template <int CH>
+__global__ __launch_bounds__(256) void k_hgt_bwd_dst(HgtTable t, HgtArgs a, const float* __restrict__ dm, int64_t ld_dm,
+                                                     const float* __restrict__ mo, int64_t ld_mo,
+                                                     const float* __restrict__ m_in, const float* __restrict__ linv_in,
+                                                     float* __restrict__ dq, int64_t ld_dq) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int vb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int row = vb * 4 + wave;
+  if (row >= a.n_rows) return;
+  const int D = a.H / a.heads;
+  const int gl = D >> 2;
+  bool on[CH], lead[CH];
+  int head[CH];
+  float4 qv[CH], dmv[CH], dqa[CH];
+  float mrow[CH], linv[CH], dsum[CH];
+  const float4* qp = reinterpret_cast<const float4*>(a.q + static_cast<int64_t>(row) * a.ld_q);
+  const float4* dp = reinterpret_cast<const float4*>(dm + static_cast<int64_t>(row) * ld_dm);
+  const float4* mp = reinterpret_cast<const float4*>(mo + static_cast<int64_t>(row) * ld_mo);
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int f = c * 256 + lane * 4;
+    on[c] = f < a.H;
+    head[c] = on[c] ? f / D : 0;
+    lead[c] = on[c] && (f % D) == 0;
+    qv[c] = on[c] ? qp[c * 64 + lane] : f4z();
+    dmv[c] = on[c] ? dp[c * 64 + lane] : f4z();
+    const float4 mv = on[c] ? mp[c * 64 + lane] : f4z();
+    dsum[c] = group_sum(dot4(dmv[c], mv), gl);                       // sum_e alpha_e dalpha_e = <dM, M>
+    mrow[c] = m_in[static_cast<int64_t>(row) * a.heads + head[c]];
+    linv[c] = linv_in[static_cast<int64_t>(row) * a.heads + head[c]];
+    dqa[c] = f4z();
+  }
+  for (int r = 0; r < t.n_rel; ++r) {
+    const agnn_hgt_rel_t& R = t.r[r];
+    const int start = R.rowptr[row];
+    const int end = (R.rowend != nullptr) ? R.rowend[row] : R.rowptr[row + 1];
+    float ps[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) ps[c] = R.pscale[head[c]];
+    for (int p = start; p < end; ++p) {
+      const int j = __builtin_amdgcn_readfirstlane(R.col[p]);
+      const int64_t e = __builtin_amdgcn_readfirstlane(R.perm[p]);
+      const float4* kp = reinterpret_cast<const float4*>(R.k + static_cast<int64_t>(j) * R.ld);
+      const float4* vp = reinterpret_cast<const float4*>(R.v + static_cast<int64_t>(j) * R.ld);
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const float4 kv = on[c] ? kp[c * 64 + lane] : f4z();
+        const float4 vv = on[c] ? vp[c * 64 + lane] : f4z();
+        const float dot = group_sum(dot4(qv[c], kv), gl);
+        const float alpha = expf(dot * ps[c] - mrow[c]) * linv[c];
+        const float da = group_sum(dot4(dmv[c], vv), gl);
+        const float ds = alpha * (da - dsum[c]);
+        const float g = ds * ps[c];
+        dqa[c].x = fmaf(g, kv.x, dqa[c].x);
+        dqa[c].y = fmaf(g, kv.y, dqa[c].y);
+        dqa[c].z = fmaf(g, kv.z, dqa[c].z);
+        dqa[c].w = fmaf(g, kv.w, dqa[c].w);
+        if (lead[c]) {
+          R.alpha[e * a.heads + head[c]] = alpha;
+          R.gs[e * a.heads + head[c]] = g;
+          R.tdot[e * a.heads + head[c]] = ds * dot;
+        }
+      }
+    }
+  }
+  float4* op = reinterpret_cast<float4*>(dq + static_cast<int64_t>(row) * ld_dq);
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+    if (on[c]) op[c * 64 + lane] = dqa[c];
+}
+
+// Pass by source (one relation, transposed CSR: rows = source nodes, col = destination rows):
+//   dV'[j] = sum_e alpha_e dM[i(e)]   ;   dK'[j] = sum_e gs_e q[i(e)]     (per head)
+template <int CH>
+__global__ __launch_bounds__(256) void k_hgt_bwd_src(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend,
+                                                     const int32_t* __restrict__ col, const int32_t* __restrict__ perm,
+                                                     const float* __restrict__ alpha, const float* __restrict__ gs, HgtArgs a,
+                                                     const float* __restrict__ dm, int64_t ld_dm, float* __restrict__ dk,
+                                                     float* __restrict__ dv, int64_t ld_o) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int vb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int row = vb * 4 + wave;
+  if (row >= a.n_rows) return;
+  const int D = a.H / a.heads;
+  bool on[CH];
+  int head[CH];
+  float4 dka[CH], dva[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int f = c * 256 + lane * 4;
+    on[c] = f < a.H;
+    head[c] = on[c] ? f / D : 0;
+    dka[c] = f4z();
+    dva[c] = f4z();
+  }
+  const int start = rowptr[row];
+  const int end = (rowend != nullptr) ? rowend[row] : rowptr[row + 1];
+  for (int p = start; p < end; ++p) {
+    const int i = __builtin_amdgcn_readfirstlane(col[p]);
+    if (i >= a.col_limit) continue;
+    const int64_t e = __builtin_amdgcn_readfirstlane(perm[p]);
+    const float4* qp = reinterpret_cast<const float4*>(a.q + static_cast<int64_t>(i) * a.ld_q);
+    const float4* dp = reinterpret_cast<const float4*>(dm + static_cast<int64_t>(i) * ld_dm);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (!on[c]) continue;
+      const float al = alpha[e * a.heads + head[c]];
+      const float g = gs[e * a.heads + head[c]];
+      const float4 qv = qp[c * 64 + lane];
+      const float4 dv4 = dp[c * 64 + lane];
+      dva[c].x = fmaf(al, dv4.x, dva[c].x); dva[c].y = fmaf(al, dv4.y, dva[c].y);
+      dva[c].z = fmaf(al, dv4.z, dva[c].z); dva[c].w = fmaf(al, dv4.w, dva[c].w);
+      dka[c].x = fmaf(g, qv.x, dka[c].x); dka[c].y = fmaf(g, qv.y, dka[c].y);
+      dka[c].z = fmaf(g, qv.z, dka[c].z); dka[c].w = fmaf(g, qv.w, dka[c].w);
+    }
+  }
+  float4* okp = reinterpret_cast<float4*>(dk + static_cast<int64_t>(row) * ld_o);
+  float4* ovp = reinterpret_cast<float4*>(dv + static_cast<int64_t>(row) * ld_o);
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    if (!on[c]) continue;
+    okp[c * 64 + lane] = dka[c];
+    ovp[c * 64 + lane] = dva[c];
+  }
+}
+
+int check_shape(const char* who, int64_t n_rows, int32_t H, int32_t heads) {
+  using namespace agnn;
+  if (n_rows < 0 || n_rows >= (int64_t{1} << 31)) return fail(AGNN_EINVAL, "%s: n_rows=%lld", who, (long long)n_rows);
+  if (H <= 0 || (H & 3) || H > 1024) return fail(AGNN_EINVAL, "%s: H=%d must be a multiple of 4 in [4,1024]", who, H);
+  if (heads <= 0 || H % heads) return fail(AGNN_EINVAL, "%s: heads=%d must divide H=%d", who, heads, H);
+  const int D = H / heads;
+  const int gl = D / 4;
+  if ((D & 3) || gl > 64 || (gl & (gl - 1)) || (256 % D != 0 && D % 256 != 0))
+    return fail(AGNN_EINVAL, "%s: head dim D=%d must be 4*2^k, at most 256, and must not straddle a 256-float chunk", who, D);
+  return AGNN_OK;
+}
+
+inline unsigned grid_for(int64_t n_rows) { return static_cast<unsigned>((((n_rows + 3) / 4) + 7) & ~int64_t{7}); }
+
+}  // namespace
+
+extern "C" int agnn_hgt_attn_fwd_f32(int n_rel, const agnn_hgt_rel_t* rels, const float* q, int64_t ld_q, int64_t n_rows,
+                                     int32_t H, int32_t heads, float* out, int64_t ld_out, float* m_out, float* linv_out,
+                                     agnn_stream_t stream_) {
+  using namespace agnn;
+  if (int rc = check_shape("hgt_fwd", n_rows, H, heads)) return rc;
+  if (n_rel < 0 || n_rel > AGNN_MAX_SEG) return fail(AGNN_EINVAL, "hgt_fwd: n_rel=%d", n_rel);
+  if (n_rows == 0) return AGNN_OK;
+  if (!q || !out || !m_out || !linv_out || (n_rel > 0 && !rels)) return fail(AGNN_EINVAL, "hgt_fwd: null argument");
+  if (!aligned16(q) || !aligned16(out) || (ld_q & 3) || (ld_out & 3)) return fail(AGNN_EALIGN, "hgt_fwd: q/out misaligned");
+  HgtTable t{};
+  t.n_rel = n_rel;
+  for (int r = 0; r < n_rel; ++r) {
+    if (!rels[r].rowptr || !rels[r].pscale) return fail(AGNN_EINVAL, "hgt_fwd: relation %d incomplete", r);
+    if ((rels[r].k && !aligned16(rels[r].k)) || (rels[r].v && !aligned16(rels[r].v)) || (rels[r].ld & 3)) return fail(AGNN_EALIGN, "hgt_fwd: relation %d k/v misaligned", r);
+    t.r[r] = rels[r];
+  }
+  HgtArgs a{q, ld_q, static_cast<int32_t>(n_rows), H, heads, INT32_MAX};
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  const dim3 grid(grid_for(n_rows)), block(256);
+  if (H <= 256) hipLaunchKernelGGL(k_hgt_fwd<1>, grid, block, 0, s, t, a, out, ld_out, m_out, linv_out);
+  else if (H <= 512) hipLaunchKernelGGL(k_hgt_fwd<2>, grid, block, 0, s, t, a, out, ld_out, m_out, linv_out);
+  else hipLaunchKernelGGL(k_hgt_fwd<4>, grid, block, 0, s, t, a, out, ld_out, m_out, linv_out);
+  return check_launch("hgt_fwd");
+}
+
+extern "C" int agnn_hgt_attn_bwd_dst_f32(int n_rel, const agnn_hgt_rel_t* rels, const float* q, int64_t ld_q, const float* dm,
+                                         int64_t ld_dm, const float* out, int64_t ld_out, const float* m_in,
+                                         const float* linv_in, int64_t n_rows, int32_t H, int32_t heads, float* dq,
+                                         int64_t ld_dq, agnn_stream_t stream_) {
+  using namespace agnn;
+  if (int rc = check_shape("hgt_bwd_dst", n_rows, H, heads)) return rc;
+  if (n_rel < 0 || n_rel > AGNN_MAX_SEG) return fail(AGNN_EINVAL, "hgt_bwd_dst: n_rel=%d", n_rel);
+  if (n_rows == 0) return AGNN_OK;
+  if (!q || !dm || !out || !m_in || !linv_in || !dq || (n_rel > 0 && !rels)) return fail(AGNN_EINVAL, "hgt_bwd_dst: null argument");
+  if (!aligned16(q) || !aligned16(dm) || !aligned16(out) || !aligned16(dq) || (ld_q & 3) || (ld_dm & 3) || (ld_out & 3) || (ld_dq & 3))
+    return fail(AGNN_EALIGN, "hgt_bwd_dst: misaligned matrix");
+  HgtTable t{};
+  t.n_rel = n_rel;
+  for (int r = 0; r < n_rel; ++r) {
+    if (!rels[r].rowptr || !rels[r].pscale || !rels[r].perm || !rels[r].alpha || !rels[r].gs || !rels[r].tdot)
+      return fail(AGNN_EINVAL, "hgt_bwd_dst: relation %d incomplete", r);
+    t.r[r] = rels[r];
+  }
+  HgtArgs a{q, ld_q, static_cast<int32_t>(n_rows), H, heads, INT32_MAX};
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  const dim3 grid(grid_for(n_rows)), block(256);
+  if (H <= 256) hipLaunchKernelGGL(k_hgt_bwd_dst<1>, grid, block, 0, s, t, a, dm, ld_dm, out, ld_out, m_in, linv_in, dq, ld_dq);
+  else if (H <= 512) hipLaunchKernelGGL(k_hgt_bwd_dst<2>, grid, block, 0, s, t, a, dm, ld_dm, out, ld_out, m_in, linv_in, dq, ld_dq);
+  else hipLaunchKernelGGL(k_hgt_bwd_dst<4>, grid, block, 0, s, t, a, dm, ld_dm, out, ld_out, m_in, linv_in, dq, ld_dq);
+  return check_launch("hgt_bwd_dst");
+}
+
+extern "C" int agnn_hgt_attn_bwd_src_f32(const int32_t* rowptr, const int32_t* rowend, const int32_t* col, const int32_t* perm,
+                                         const float* alpha, const float* gs, const float* q, int64_t ld_q, const float* dm,
+                                         int64_t ld_dm, int64_t n_src_rows, int32_t col_limit, int32_t H, int32_t heads,
+                                         float* dk, float* dv, int64_t ld_o, agnn_stream_t stream_) {
+  using namespace agnn;
+  if (int rc = check_shape("hgt_bwd_src", n_src_rows, H, heads)) return rc;
+  if (n_src_rows == 0) return AGNN_OK;
+  if (!rowptr || !dk || !dv) return fail(AGNN_EINVAL, "hgt_bwd_src: null argument");
+  if (!aligned16(dk) || !aligned16(dv) || (ld_o & 3) || (q && (!aligned16(q) || (ld_q & 3))) || (dm && (!aligned16(dm) || (ld_dm & 3))))
+    return fail(AGNN_EALIGN, "hgt_bwd_src: misaligned matrix");
+  HgtArgs a{q, ld_q, static_cast<int32_t>(n_src_rows), H, heads, col_limit};
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  const dim3 grid(grid_for(n_src_rows)), block(256);
+  if (H <= 256) hipLaunchKernelGGL(k_hgt_bwd_src<1>, grid, block, 0, s, rowptr, rowend, col, perm, alpha, gs, a, dm, ld_dm, dk, dv, ld_o);
+  else if (H <= 512) hipLaunchKernelGGL(k_hgt_bwd_src<2>, grid, block, 0, s, rowptr, rowend, col, perm, alpha, gs, a, dm, ld_dm, dk, dv, ld_o);
+  else hipLaunchKernelGGL(k_hgt_bwd_src<4>, grid, block, 0, s, rowptr, rowend, col, perm, alpha, gs, a, dm, ld_dm, dk, dv, ld_o);
+  return check_launch("hgt_bwd_src");
+}

@@ -1,0 +1,249 @@
+"""HGT path: `HGTConv` with PyG (>= 2.3) parameter names and semantics, the
+layer stack, and the `HybridHGT` encoder the reference constructs at
+analysisgnn/models/analysis.py:445-453 (`heads=4`).  The per-edge work (scores, edge softmax over all
+incoming relations, weighted sum, and their gradients) runs on the C-ABI kernels
+`agnn_hgt_attn_*`; the per-type K/Q/V and output projections and the per-(relation, head) D x D
+transforms are library GEMMs.  Build-spec notes (parity unpinned vs graphmuse): encoders.py header."""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from .encoders import TrimPlan, _HybridMixin
+from .graph import Csr, HeteroIndex, hetero_index
+
+EdgeType = Tuple[str, str, str]
+
+
+class _AttnSpec:
+    def __init__(self, fwd: List[Csr], bwd: List[Csr], n_rows: int, heads: int, n_edges: List[int],
+                 e_limit: Optional[List[Optional[int]]], src_rows: List[int]):
+        self.fwd, self.bwd, self.n_rows, self.heads = fwd, bwd, n_rows, heads
+        self.n_edges, self.e_limit, self.src_rows = n_edges, e_limit, src_rows
+
+    def limit(self, r):
+        return None if self.e_limit is None else self.e_limit[r]
+
+
+def _mat(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32 or t.dim() != 2:
+        raise _lib.AgnnError("fp32 2-D matrix expected")
+    if t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16:
+        t = t.contiguous()
+    return t
+
+
+class _HGTAttention(torch.autograd.Function):
+    """M = edge_softmax_attention(q; {k'_r, v'_r}); inputs: q [N_d,H], pscale [R,heads], then k'_0, v'_0, k'_1, ..."""
+
+    @staticmethod
+    def forward(ctx, spec: _AttnSpec, q, pscale, *kv):
+        dev = _lib.require_gpu(q, pscale, *kv)
+        lib = _lib.load()
+        R = len(spec.fwd)
+        n, H, heads = spec.n_rows, q.shape[1], spec.heads
+        q = _mat(q)
+        pscale = pscale.contiguous()
+        ks = [_mat(kv[2 * r]) for r in range(R)]
+        vs = [_mat(kv[2 * r + 1]) for r in range(R)]
+        out = torch.empty((n, H), dtype=torch.float32, device=dev)
+        m = torch.empty((max(n, 1), heads), dtype=torch.float32, device=dev)
+        linv = torch.empty((max(n, 1), heads), dtype=torch.float32, device=dev)
+        rels = (_lib.HgtRel * max(R, 1))()
+        keep = []
+        for r in range(R):
+            c = spec.fwd[r]
+            re = c.rowend(spec.limit(r))
+            keep.append(re)
+            if ks[r].stride(0) != vs[r].stride(0):
+                vs[r] = vs[r].contiguous()
+                ks[r] = ks[r].contiguous()
+            rels[r].k, rels[r].v = ks[r].data_ptr(), vs[r].data_ptr()
+            rels[r].rowptr, rels[r].rowend = c.rowptr.data_ptr(), _lib.ptr(re)
+            rels[r].col, rels[r].perm = c.col.data_ptr(), c.perm.data_ptr()
+            rels[r].pscale = pscale[r].data_ptr()
+            rels[r].ld = ks[r].stride(0)
+        if n > 0:
+            _lib.check(lib.agnn_hgt_attn_fwd_f32(R, rels, q.data_ptr(), q.stride(0), n, H, heads, out.data_ptr(),
+                                                 out.stride(0), m.data_ptr(), linv.data_ptr(), _lib.stream_ptr(dev)),
+                       "agnn_hgt_attn_fwd_f32")
+        ctx.spec = spec
+        ctx.save_for_backward(q, pscale, out, m, linv, *ks, *vs)
+        return out
+
+    @staticmethod
+    def backward(ctx, dm):
+        spec: _AttnSpec = ctx.spec
+        q, pscale, out, m, linv, *rest = ctx.saved_tensors
+        R = len(spec.fwd)
+        ks, vs = rest[:R], rest[R:]
+        dev = dm.device
+        lib = _lib.load()
+        n, H, heads = spec.n_rows, q.shape[1], spec.heads
+        dm = _mat(dm)
+        dq = torch.zeros_like(q)
+        alpha = [torch.zeros((max(spec.n_edges[r], 1), heads), dtype=torch.float32, device=dev) for r in range(R)]
+        gs = [torch.zeros_like(a) for a in alpha]
+        tdot = [torch.zeros_like(a) for a in alpha]
+        rels = (_lib.HgtRel * max(R, 1))()
+        keep = []
+        for r in range(R):
+            c = spec.fwd[r]
+            re = c.rowend(spec.limit(r))
+            keep.append(re)
+            rels[r].k, rels[r].v = ks[r].data_ptr(), vs[r].data_ptr()
+            rels[r].rowptr, rels[r].rowend = c.rowptr.data_ptr(), _lib.ptr(re)
+            rels[r].col, rels[r].perm = c.col.data_ptr(), c.perm.data_ptr()
+            rels[r].pscale = pscale[r].data_ptr()
+            rels[r].ld = ks[r].stride(0)
+            rels[r].alpha, rels[r].gs, rels[r].tdot = alpha[r].data_ptr(), gs[r].data_ptr(), tdot[r].data_ptr()
+        if n > 0:
+            _lib.check(lib.agnn_hgt_attn_bwd_dst_f32(R, rels, q.data_ptr(), q.stride(0), dm.data_ptr(), dm.stride(0),
+                                                     out.data_ptr(), out.stride(0), m.data_ptr(), linv.data_ptr(), n, H,
+                                                     heads, dq.data_ptr(), dq.stride(0), _lib.stream_ptr(dev)),
+                       "agnn_hgt_attn_bwd_dst_f32")
+        dps = torch.stack([t.sum(dim=0) for t in tdot]) if R else torch.zeros_like(pscale)
+        grads = []
+        for r in range(R):
+            c = spec.bwd[r]
+            n_src = spec.src_rows[r]
+            dk = torch.empty((n_src, H), dtype=torch.float32, device=dev)
+            dv = torch.empty((n_src, H), dtype=torch.float32, device=dev)
+            re = c.rowend(spec.limit(r))
+            lim = n if spec.fwd[r].n_rows > n else _lib.INT32_MAX
+            if n_src > 0:
+                _lib.check(lib.agnn_hgt_attn_bwd_src_f32(c.rowptr.data_ptr(), _lib.ptr(re), c.col.data_ptr(),
+                                                         c.perm.data_ptr(), alpha[r].data_ptr(), gs[r].data_ptr(),
+                                                         q.data_ptr(), q.stride(0), dm.data_ptr(), dm.stride(0), n_src, lim,
+                                                         H, heads, dk.data_ptr(), dv.data_ptr(), dk.stride(0),
+                                                         _lib.stream_ptr(dev)), "agnn_hgt_attn_bwd_src_f32")
+            grads += [dk, dv]
+        return (None, dq, dps, *grads)
+
+
+class _DictLinear(nn.Module):
+    """`HeteroDictLinear`: one Linear per node type, parameters under `lins.<type>`."""
+
+    def __init__(self, in_channels, out_channels, types: Sequence[str]):
+        super().__init__()
+        self.lins = nn.ModuleDict({t: nn.Linear(in_channels, out_channels) for t in types})
+
+    def forward(self, x_dict):
+        return {k: self.lins[k](v) for k, v in x_dict.items() if k in self.lins}
+
+
+class _RelWeight(nn.Module):
+    """`HeteroLinear(D, D, num_types=heads*edge_types, bias=False)`: weight [T, D, D], y = x @ W[type]."""
+
+    def __init__(self, num_types, dim):
+        super().__init__()
+        bound = 1.0 / math.sqrt(dim)
+        self.weight = nn.Parameter(torch.empty(num_types, dim, dim).uniform_(-bound, bound))
+
+
+class HGTConv(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, metadata, heads: int = 1):
+        super().__init__()
+        if out_channels % heads:
+            raise ValueError("out_channels must be divisible by heads")
+        self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
+        self.node_types = list(metadata[0])
+        self.edge_types = [tuple(e) for e in metadata[1]]
+        D = out_channels // heads
+        self.kqv_lin = _DictLinear(in_channels, out_channels * 3, self.node_types)
+        self.out_lin = _DictLinear(out_channels, out_channels, self.node_types)
+        self.k_rel = _RelWeight(heads * len(self.edge_types), D)
+        self.v_rel = _RelWeight(heads * len(self.edge_types), D)
+        self.skip = nn.ParameterDict({t: nn.Parameter(torch.ones(1)) for t in self.node_types})
+        self.p_rel = nn.ParameterDict({"__".join(e): nn.Parameter(torch.ones(1, heads)) for e in self.edge_types})
+
+    def forward(self, x_dict, edge_index_dict, index: Optional[HeteroIndex] = None,
+                n_keep: Optional[Dict[str, int]] = None, e_keep: Optional[Dict[EdgeType, Optional[int]]] = None):
+        _lib.require_gpu(*x_dict.values())
+        if index is None:
+            index = hetero_index(edge_index_dict, {k: int(v.shape[0]) for k, v in x_dict.items()})
+        heads, H = self.heads, self.out_channels
+        D = H // heads
+        n_of = {t: (n_keep[t] if n_keep is not None else int(x.shape[0])) for t, x in x_dict.items()}
+        kqv = {t: self.kqv_lin.lins[t](x[:n_of[t]]) for t, x in x_dict.items()}
+        k = {t: v[:, :H] for t, v in kqv.items()}
+        q = {t: v[:, H:2 * H] for t, v in kqv.items()}
+        v = {t: v[:, 2 * H:] for t, v in kqv.items()}
+        by_dst: Dict[str, List[Tuple[int, EdgeType]]] = {}
+        for e_idx, et in enumerate(self.edge_types):
+            s, _, d = et
+            if et in index.fwd and s in x_dict and d in x_dict:
+                by_dst.setdefault(d, []).append((e_idx, et))
+        out = {}
+        for t, x in x_dict.items():
+            n = n_of[t]
+            rels = by_dst.get(t, [])
+            if rels and n > 0:
+                kv, ps = [], []
+                for e_idx, et in rels:
+                    s = et[0]
+                    Wk = self.k_rel.weight[e_idx * heads:(e_idx + 1) * heads]
+                    Wv = self.v_rel.weight[e_idx * heads:(e_idx + 1) * heads]
+                    ns = k[s].shape[0]
+                    k2 = torch.bmm(k[s].reshape(ns, heads, D).transpose(0, 1), Wk).transpose(0, 1).reshape(ns, H)
+                    v2 = torch.bmm(v[s].reshape(ns, heads, D).transpose(0, 1), Wv).transpose(0, 1).reshape(ns, H)
+                    kv += [k2, v2]
+                    ps.append(self.p_rel["__".join(et)].reshape(heads) / math.sqrt(D))
+                spec = _AttnSpec(fwd=[index.fwd[et] for _, et in rels], bwd=[index.bwd[et] for _, et in rels], n_rows=n,
+                                 heads=heads, n_edges=[index.num_edges[et] for _, et in rels],
+                                 e_limit=[e_keep[et] for _, et in rels] if e_keep is not None else None,
+                                 src_rows=[kv[2 * i].shape[0] for i in range(len(rels))])
+                m = _HGTAttention.apply(spec, q[t], torch.stack(ps), *kv)
+            else:
+                m = x.new_zeros((n, H))
+            o = self.out_lin.lins[t](F.gelu(m))
+            if o.shape[-1] == x.shape[-1]:
+                beta = torch.sigmoid(self.skip[t])
+                o = beta * o + (1 - beta) * x[:n]
+            out[t] = o
+        return out
+
+
+class HeteroHGTStack(nn.Module):
+    def __init__(self, metadata, input_channels, hidden_channels, num_layers, heads=4, dropout=0.5):
+        super().__init__()
+        self.num_layers, self.dropout = num_layers, dropout
+        self.convs = nn.ModuleList([HGTConv(input_channels if i == 0 else hidden_channels, hidden_channels, metadata, heads)
+                                    for i in range(num_layers)])
+
+    def forward(self, x_dict, edge_index_dict, plan: TrimPlan, collect: Optional[list] = None):
+        index = hetero_index(edge_index_dict, {k: int(v.shape[0]) for k, v in x_dict.items()})
+        for i, conv in enumerate(self.convs):
+            x_dict = conv(x_dict, edge_index_dict, index, plan.n_keep[i], plan.e_keep[i])
+            if i < self.num_layers - 1:
+                x_dict = {k: F.dropout(F.relu(v), self.dropout, self.training) for k, v in x_dict.items()}
+            if collect is not None:
+                collect.append(x_dict["note"])
+        return x_dict
+
+
+class HybridHGT(nn.Module, _HybridMixin):
+    """analysis.py:445-453 constructor (`heads=4`); forward keywords analysis.py:576-579."""
+
+    def __init__(self, metadata, input_channels, hidden_channels, num_layers, heads=4, dropout=0.5, use_jk=False, **kwargs):
+        super().__init__()
+        self.metadata = (list(metadata[0]), [tuple(e) for e in metadata[1]])
+        self.num_layers = num_layers
+        self.gnn = HeteroHGTStack(self.metadata, input_channels, hidden_channels, num_layers, heads, dropout)
+        self._init_hybrid(input_channels, hidden_channels, num_layers, dropout, use_jk)
+
+    def forward(self, x_dict, edge_index_dict, batch_dict=None, batch_size=None, neighbor_mask_node=None,
+                neighbor_mask_edge=None, return_edge_index=False, edge_attr_dict=None):
+        _lib.require_gpu(*x_dict.values())
+        if batch_size is None:
+            batch_size = int(x_dict["note"].shape[0])
+        plan = TrimPlan(self.num_layers, x_dict, edge_index_dict, neighbor_mask_node, neighbor_mask_edge)
+        outs: list = []
+        h = self.gnn(x_dict, edge_index_dict, plan, outs)
+        out = self._finish(h["note"], outs, x_dict["note"], batch_dict, batch_size)
+        return (out, edge_index_dict) if return_edge_index else out

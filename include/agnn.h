@@ -15,6 +15,8 @@
  *                         models/analysis.py:580-586) and PyG `SAGEConv` mean aggregation under
  *                         `HeteroConv` (ref: models/cadence.py:147-159,174)
  *   agnn_gru_fwd/bwd_f32  `torch.nn.GRU` of the hybrid sequence branch (ref: models/cadence.py:249-285)
+ *   agnn_hgt_attn_*       PyG `HGTConv` message/softmax/aggregate, reached through graphmuse
+ *                         `HybridHGT` (ref: models/analysis.py:445-453)
  *
  * Conventions (all entry points)
  *   - plain pointers and sizes only; every `const T*`/`T*` marked (device) is device memory owned
@@ -136,6 +138,47 @@ int agnn_gru_fwd_f32(const float* gi, const float* w_hh, const float* b_hh, int6
 int agnn_gru_bwd_f32(const float* dy, const float* y, const float* saved, const float* w_hh,
                      int64_t B, int64_t T, int32_t hidden, float* dgi, float* dhn,
                      agnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * HGT edge-softmax attention = message / softmax / aggregate of PyG `HGTConv`, reached through
+ * graphmuse `HybridHGT` (ref: models/analysis.py:445-453; semantics SURVEY.md App. A.4).
+ * For destination row i, head h (D = H / heads floats per head), over ALL incoming edges e of all
+ * n_rel relations:   s_e = <q_i,h, k_r[col_e],h> * pscale_r[h]      (pscale = p_rel / sqrt(D))
+ *                    a_e = exp(s_e - max) / (sum exp(s_e - max) + 1e-16),   out_i,h = sum_e a_e v_r[col_e],h
+ * k_r / v_r are the relation-transformed keys / values of the source type (dense GEMMs by the caller).
+ * m_out / linv_out [n_rows, heads] keep the row max and 1/(sum + 1e-16) for the backward pass.
+ * D must be 4*2^k, <= 256.
+ * Backward, pass by destination: dq plus per-edge alpha, gs = ds*pscale, tdot = ds*<q,k> written at the
+ * edge's COO position perm[p] into [n_edges, heads] arrays of its relation.
+ * Backward, pass by source (one relation, transposed CSR, col = destination row, rows >= col_limit
+ * skipped): dv[j] = sum_e alpha_e dm[col_e], dk[j] = sum_e gs_e q[col_e].
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* k;          /* (device) [n_src, ld] */
+  const float* v;          /* (device) [n_src, ld] */
+  const int32_t* rowptr;   /* (device) [n_rows + 1] */
+  const int32_t* rowend;   /* (device) [n_rows] or NULL */
+  const int32_t* col;      /* (device) */
+  const int32_t* perm;     /* (device) COO position of every CSR position (backward only) */
+  const float* pscale;     /* (device) [heads] */
+  int64_t ld;
+  float* alpha;            /* (device) [n_edges, heads]  backward outputs */
+  float* gs;               /* (device) [n_edges, heads] */
+  float* tdot;             /* (device) [n_edges, heads] */
+} agnn_hgt_rel_t;
+
+int agnn_hgt_attn_fwd_f32(int n_rel, const agnn_hgt_rel_t* rels /* (host) */, const float* q, int64_t ld_q,
+                          int64_t n_rows, int32_t H, int32_t heads, float* out, int64_t ld_out,
+                          float* m_out, float* linv_out, agnn_stream_t stream);
+int agnn_hgt_attn_bwd_dst_f32(int n_rel, const agnn_hgt_rel_t* rels /* (host) */, const float* q, int64_t ld_q,
+                              const float* dm, int64_t ld_dm, const float* out, int64_t ld_out,
+                              const float* m_in, const float* linv_in, int64_t n_rows, int32_t H,
+                              int32_t heads, float* dq, int64_t ld_dq, agnn_stream_t stream);
+int agnn_hgt_attn_bwd_src_f32(const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
+                              const int32_t* perm, const float* alpha, const float* gs, const float* q,
+                              int64_t ld_q, const float* dm, int64_t ld_dm, int64_t n_src_rows,
+                              int32_t col_limit, int32_t H, int32_t heads, float* dk, float* dv,
+                              int64_t ld_o, agnn_stream_t stream);
 
 #ifdef __cplusplus
 }
