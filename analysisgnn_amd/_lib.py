@@ -61,6 +61,8 @@ SIGNATURES = {
     "agnn_hgt_attn_bwd_src_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
                                             C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "agnn_multitask_ce_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_float,
+                                        C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 

@@ -357,7 +357,6 @@ extern "C" int agnn_spmm_f32(int n_rel, const agnn_rel_t* rels, int64_t n_rows, 
     t.r[r] = rels[r];
   }
   SpmmArgs a{static_cast<int32_t>(n_rows), H, out, ld_out, rel_stride, self, ld_self, inv_cnt, col_limit, flags};
-  const int threads = 256;  // 4 waves = 4 rows per block
   int64_t blocks = ((n_rows + 3) / 4 + 7) & ~int64_t{7};   // multiple of 8: the XCD remap is a bijection
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (!(flags & AGNN_SPMM_GENERIC) && (H == 256 || H == 512) && !(flags & AGNN_SPMM_SKIP_SELF) &&

@@ -177,6 +177,16 @@ class HeteroSAGEStack(nn.Module):
 # ------------------------------------------------------------------------------------------
 # hybrid (sequence) branch — persistent GRU kernels (gru.py) for hidden 128, library RNN otherwise
 # ------------------------------------------------------------------------------------------
+_SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _SIDE_STREAMS:
+        _SIDE_STREAMS[idx] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[idx]
+
+
 class _HybridMixin:
     def _init_hybrid(self, input_channels, hidden_channels, num_layers, dropout, use_jk):
         self.use_jk = bool(use_jk)
@@ -203,15 +213,33 @@ class _HybridMixin:
         y = self.rnn_mlp(self.rnn_norm(y))
         return torch.cat(nn.utils.rnn.unpad_sequence(y, batch_first=True, lengths=lengths.cpu()), dim=0)
 
-    def _finish(self, x_note, outs, x_in, batch_dict, batch_size):
+    # The sequence branch only needs the encoder INPUT, so it runs on a second HIP stream beside the
+    # GNN stack (the persistent GRU kernels occupy 2*B of the 256 CUs and are latency bound); autograd
+    # replays the backward on the same streams.  Set to False to serialise (debugging / graph capture).
+    overlap_sequence_branch = True
+
+    def _start_branch(self, x_in, batch_dict, batch_size):
+        dev = x_in.device
+        if batch_dict is None:
+            batch_note = torch.zeros(batch_size, dtype=torch.long, device=dev)
+        else:
+            batch_note = batch_dict["note"][:batch_size]
+        if not (self.overlap_sequence_branch and x_in.is_cuda):
+            return self.hybrid_forward(x_in[:batch_size], batch_note), None
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            z = self.hybrid_forward(x_in[:batch_size], batch_note)
+        return z, side
+
+    def _finish(self, x_note, outs, z, side, batch_size):
         x = x_note[:batch_size]
         if self.use_jk:
             x = self.jk([o[:batch_size] for o in outs])
-        if batch_dict is None:
-            batch_note = torch.zeros(batch_size, dtype=torch.long, device=x.device)
-        else:
-            batch_note = batch_dict["note"][:batch_size]
-        z = self.hybrid_forward(x_in[:batch_size], batch_note)
+        if side is not None:
+            torch.cuda.current_stream(x.device).wait_stream(side)
+            z.record_stream(torch.cuda.current_stream(x.device))
         return self.cat_proj(torch.cat((x, z), dim=-1))
 
 
@@ -239,8 +267,9 @@ class HybridGNN(nn.Module, _HybridMixin):
             batch_size = int(x_dict["note"].shape[0])
         plan = TrimPlan(self.num_layers, x_dict, edge_index_dict, neighbor_mask_node, neighbor_mask_edge)
         outs: list = []
+        z, side = self._start_branch(x_dict["note"], batch_dict, batch_size)
         h = self.gnn(x_dict, edge_index_dict, plan, outs)
-        out = self._finish(h["note"], outs, x_dict["note"], batch_dict, batch_size)
+        out = self._finish(h["note"], outs, z, side, batch_size)
         return (out, edge_index_dict) if return_edge_index else out
 
 

@@ -1,0 +1,77 @@
+"""Fused task heads and fused multi-task cross entropy (the wrapper epilogue).
+
+The reference runs 21 independent `Linear -> ReLU -> LayerNorm -> Linear` heads
+(analysisgnn/models/analysis.py:486-496, :546-548) and 21 `CrossEntropyLoss(ignore_index=-1,
+label_smoothing=0.1)` terms (:881-888, models/chord.py:39-49): ~600 tiny launches per step whose
+weight-gradient GEMMs are 64 x 128 outputs with K = N (4 workgroups on a 256-CU chip).  Same parameters
+(`clf_dict.<task>.{0,2,3}` stay ordinary modules, `state_dict` unchanged), different schedule:
+  * first layers stacked into ONE GEMM  [N, o] x [o, T*h2]
+  * ReLU + LayerNorm over each task's h2-wide group in one pass on the [N, T, h2] view
+  * second layers as ONE GEMM against the block-diagonal [sum C, T*h2] weight -> logits side by side [N, sum C]
+  * one C-ABI kernel for all T cross-entropy terms and their gradient (`agnn_multitask_ce_f32`).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+
+def fused_head_logits(clf_dict: nn.ModuleDict, x: torch.Tensor, tasks: Sequence[str]) -> Tuple[torch.Tensor, List[int]]:
+    """Concatenated logits [N, sum_t C_t] of the given tasks and the segment offsets (len T+1)."""
+    mods = [clf_dict[t] for t in tasks]
+    T = len(mods)
+    h2 = mods[0][0].out_features
+    W1 = torch.cat([m[0].weight for m in mods], dim=0)                    # [T*h2, o]
+    b1 = torch.cat([m[0].bias for m in mods], dim=0)
+    a = F.relu(torch.addmm(b1, x, W1.t()))                                # [N, T*h2]
+    gamma = torch.stack([m[2].weight for m in mods])                      # [T, h2]
+    beta = torch.stack([m[2].bias for m in mods])
+    a = F.layer_norm(a.view(-1, T, h2), (h2,), None, None, mods[0][2].eps) * gamma + beta
+    W2 = torch.block_diag(*[m[3].weight for m in mods])                   # [sum C, T*h2]
+    b2 = torch.cat([m[3].bias for m in mods], dim=0)
+    logits = torch.addmm(b2, a.reshape(-1, T * h2), W2.t())
+    offs = [0]
+    for m in mods:
+        offs.append(offs[-1] + m[3].out_features)
+    return logits, offs
+
+
+class _MultiTaskCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, offs_t, eps: float, ignore_index: int):
+        dev = _lib.require_gpu(logits, labels, offs_t)
+        if logits.dtype != torch.float32 or logits.stride(1) != 1:
+            logits = logits.float().contiguous()
+        N = logits.shape[0]
+        T = offs_t.numel() - 1
+        labels = labels.contiguous()
+        cnt = (labels != ignore_index).sum(dim=1).clamp(min=1).to(torch.float32)
+        inv_cnt = 1.0 / cnt
+        row_loss = torch.empty((N, T), dtype=torch.float32, device=dev)
+        dlogits = torch.zeros_like(logits) if offs_t.numel() and logits.shape[1] != 0 else logits
+        lib = _lib.load()
+        _lib.check(lib.agnn_multitask_ce_f32(logits.data_ptr(), logits.stride(0), offs_t.data_ptr(), T, labels.data_ptr(), N,
+                                             float(eps), int(ignore_index), inv_cnt.data_ptr(), row_loss.data_ptr(),
+                                             dlogits.data_ptr(), _lib.stream_ptr(dev)), "agnn_multitask_ce_f32")
+        ctx.save_for_backward(dlogits, offs_t)
+        return row_loss.sum(dim=0) * inv_cnt                                # [T] mean loss per task
+
+    @staticmethod
+    def backward(ctx, g):
+        dlogits, offs_t = ctx.saved_tensors
+        width = dlogits.shape[1]
+        seg = torch.bucketize(torch.arange(width, device=g.device, dtype=torch.int32), offs_t[1:], right=True)
+        gcol = g[seg.clamp(max=g.numel() - 1)]
+        return dlogits * gcol.unsqueeze(0), None, None, None, None
+
+
+def multitask_cross_entropy(logits: torch.Tensor, offs: Sequence[int], labels: torch.Tensor, label_smoothing: float = 0.1,
+                            ignore_index: int = -1) -> torch.Tensor:
+    """Per-task mean losses [T] for side-by-side logits [N, sum C]; labels int64 [T, N]."""
+    offs_t = torch.tensor(list(offs), dtype=torch.int32, device=logits.device)
+    return _MultiTaskCE.apply(logits, labels, offs_t, label_smoothing, ignore_index)

@@ -12,6 +12,7 @@ import torch.nn as nn
 
 from . import _lib, ops
 from .encoders import HybridGNN, MetricalGNN
+from .heads import fused_head_logits
 from .graph import SegSpec, build_csr
 
 
@@ -82,8 +83,15 @@ class TorchAnalysisGNN(nn.Module):
         return self.project_enc(x)
 
     def forward_clf(self, x, tasks=None):
-        tasks = self.clf_dict.keys() if tasks is None else tasks
-        return {t: self.clf_dict[t](x) for t in tasks}
+        """Same dict of logits as analysis.py:546-548, computed by the fused head schedule (heads.py);
+        the values are column views of one [N, sum C] matrix."""
+        logits, offs, tasks = self.forward_clf_fused(x, tasks)
+        return {t: logits[:, offs[i]:offs[i + 1]] for i, t in enumerate(tasks)}
+
+    def forward_clf_fused(self, x, tasks=None):
+        tasks = list(self.clf_dict.keys() if tasks is None else tasks)
+        logits, offs = fused_head_logits(self.clf_dict, x, tasks)
+        return logits, offs, tasks
 
     def forward(self, pitch_spelling, key_signature, x_dict, edge_index_dict, batch_dict, batch_size,
                 neighbor_mask_node, neighbor_mask_edge):

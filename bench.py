@@ -122,11 +122,15 @@ def main():
     opt = torch.optim.AdamW(model.parameters(), lr=5e-3, weight_decay=5e-3, foreach=True)
     graph.index_cache_enabled = False                               # fresh batch every step: rebuild the CSR
 
+    from analysisgnn_amd.heads import multitask_cross_entropy
+    label_mat = torch.stack([labels[t] for t in TASK_DICT])             # [T, N]
+
     def step():
         flat.zero()
         x = model.encode(I["pitch_spelling"], I["key_signature"], I["x_dict"], I["edge_index_dict"], I["batch_dict"],
                          I["batch_size"], None, None)
-        loss = loss_fn(model.forward_clf(x), labels, x)
+        logits, offs, _ = model.forward_clf_fused(x)
+        loss = 0.1 * x.pow(2).mean() + multitask_cross_entropy(logits, offs, label_mat, 0.1, -1).sum()
         loss.backward()
         flat.all_reduce_mean()
         flat.clip_norm_(1.0)

@@ -15,6 +15,7 @@
  *                         models/analysis.py:580-586) and PyG `SAGEConv` mean aggregation under
  *                         `HeteroConv` (ref: models/cadence.py:147-159,174)
  *   agnn_gru_fwd/bwd_f32  `torch.nn.GRU` of the hybrid sequence branch (ref: models/cadence.py:249-285)
+ *   agnn_multitask_ce_f32 the 21 per-task CrossEntropyLoss terms (ref: models/analysis.py:881-888)
  *   agnn_hgt_attn_*       PyG `HGTConv` message/softmax/aggregate, reached through graphmuse
  *                         `HybridHGT` (ref: models/analysis.py:445-453)
  *
@@ -179,6 +180,19 @@ int agnn_hgt_attn_bwd_src_f32(const int32_t* rowptr, const int32_t* rowend, cons
                               int64_t ld_q, const float* dm, int64_t ld_dm, int64_t n_src_rows,
                               int32_t col_limit, int32_t H, int32_t heads, float* dk, float* dv,
                               int64_t ld_o, agnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused multi-task cross entropy (label smoothing, ignore index) over column segments of one logits
+ * matrix: replaces the per-task `nn.CrossEntropyLoss(ignore_index=-1, label_smoothing=0.1)` terms
+ * (ref: models/analysis.py:881-888, models/chord.py:39-49).  Task t owns columns [seg_off[t], seg_off[t+1]).
+ *   labels    int64 [n_tasks, n_rows]      inv_count [n_tasks] = 1 / max(#rows with label != ignore, 1)
+ *   row_loss  [n_rows, n_tasks]  per-row loss terms (0 for ignored rows); task loss = sum * inv_count
+ *   dlogits   [n_rows, ld]       d(sum_t mean-loss_t) / d logits  (columns outside the segments untouched)
+ * ------------------------------------------------------------------------------------------ */
+int agnn_multitask_ce_f32(const float* logits, int64_t ld, const int32_t* seg_off, int32_t n_tasks,
+                          const int64_t* labels, int64_t n_rows, float label_smoothing,
+                          int64_t ignore_index, const float* inv_count, float* row_loss, float* dlogits,
+                          agnn_stream_t stream);
 
 #ifdef __cplusplus
 }

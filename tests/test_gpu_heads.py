@@ -1,0 +1,74 @@
+"""Fused task heads and fused multi-task cross entropy vs plain PyTorch fp32 on CPU (the per-task modules and
+`F.cross_entropy(ignore_index=-1, label_smoothing=0.1)` the reference uses, analysis.py:486-496, :881-888).
+Tolerance 1e-4 relative to max(1,|ref|max); observed ~1e-6."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from helpers import assert_close  # noqa: E402
+
+DEV = "cuda:0"
+TASKS = {"cadence": 4, "localkey": 50, "hrythm": 2, "romanNumeral": 185, "pcset": 94}
+
+
+def _clf(o=32):
+    import torch.nn as nn
+    torch.manual_seed(0)
+    return nn.ModuleDict({t: nn.Sequential(nn.Linear(o, o // 2), nn.ReLU(), nn.LayerNorm(o // 2), nn.Linear(o // 2, c))
+                          for t, c in TASKS.items()})
+
+
+def test_fused_heads_and_loss_match_per_task_modules():
+    import copy
+    from analysisgnn_amd.heads import fused_head_logits, multitask_cross_entropy
+    N = 301
+    clf = _clf()
+    with torch.no_grad():
+        for m in clf.values():
+            m[2].weight.uniform_(0.5, 1.5)
+            m[2].bias.uniform_(-0.3, 0.3)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, 32, generator=g)
+    labels = {t: torch.randint(0, c, (N,), generator=g) for t, c in TASKS.items()}
+    labels["localkey"][::7] = -1                         # ignored rows
+    labels["hrythm"][:] = -1                             # a task with no valid row at all
+    # reference: per-task modules + F.cross_entropy on CPU
+    xr = x.clone().requires_grad_(True)
+    ref_losses = []
+    for t in TASKS:
+        ref_losses.append(F.cross_entropy(clf[t](xr), labels[t], ignore_index=-1, label_smoothing=0.1))
+    ref_losses = torch.stack([torch.nan_to_num(l, nan=0.0) for l in ref_losses])
+    w = torch.tensor([1.0, 0.5, 2.0, 1.5, 0.25])
+    (ref_losses * w).sum().backward()
+    # fused on the GPU
+    clg = copy.deepcopy(clf).to(DEV)
+    for p in clg.parameters():
+        p.grad = None
+    xg = x.to(DEV).requires_grad_(True)
+    logits, offs = fused_head_logits(clg, xg, list(TASKS))
+    assert logits.shape == (N, sum(TASKS.values())) and offs[-1] == sum(TASKS.values())
+    for i, t in enumerate(TASKS):
+        assert_close(logits[:, offs[i]:offs[i + 1]], clf[t](x), 1e-4, f"logits[{t}]")
+    lab = torch.stack([labels[t] for t in TASKS]).to(DEV)
+    losses = multitask_cross_entropy(logits, offs, lab, 0.1, -1)
+    assert_close(losses, ref_losses, 1e-4, "losses")
+    (losses * w.to(DEV)).sum().backward()
+    assert_close(xg.grad, xr.grad, 1e-4, "dx")
+    for (n, p), (_, q) in zip(clg.named_parameters(), clf.named_parameters()):
+        if q.grad is None:
+            continue
+        assert_close(p.grad, q.grad, 1e-4, f"d{n}")
+
+
+def test_model_forward_clf_is_dict_of_views():
+    from analysisgnn_amd.models import TorchAnalysisGNN
+    from analysisgnn_amd.synth import make_batch
+    g = make_batch(1, 30)
+    m = TorchAnalysisGNN(g.metadata(), 25, 32, 16, {"a": 3, "b": 7}, 2, dropout=0.0, use_jk=False).to(DEV)
+    x = torch.randn(11, 16, device=DEV)
+    out = m.forward_clf(x)
+    assert list(out) == ["a", "b"] and out["a"].shape == (11, 3) and out["b"].shape == (11, 7)
+    assert_close(out["b"], m.clf_dict["b"](x), 1e-5)
+    assert list(m.forward_clf(x, tasks=["b"])) == ["b"]
