@@ -36,6 +36,12 @@ class HgtRel(C.Structure):
                 ("alpha", C.c_void_p), ("gs", C.c_void_p), ("tdot", C.c_void_p)]
 
 
+class Gated(C.Structure):
+    _fields_ = [("rowptr", C.c_void_p), ("col", C.c_void_p), ("perm", C.c_void_p), ("a", C.c_void_p), ("b", C.c_void_p),
+                ("h", C.c_void_p), ("c", C.c_void_p), ("ld", C.c_int64), ("ld_c", C.c_int64), ("n_rows", C.c_int64),
+                ("H", C.c_int32)]
+
+
 _lib: Optional[C.CDLL] = None
 
 # every exported symbol of include/agnn.h: (name, restype, argtypes)
@@ -61,6 +67,9 @@ SIGNATURES = {
     "agnn_hgt_attn_bwd_src_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
                                             C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "agnn_gated_fwd_f32": (C.c_int, [C.POINTER(Gated), C.c_void_p, C.c_int64, C.c_void_p]),
+    "agnn_gated_bwd_dst_f32": (C.c_int, [C.POINTER(Gated), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "agnn_gated_bwd_src_f32": (C.c_int, [C.POINTER(Gated), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "agnn_multitask_ce_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_float,
                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

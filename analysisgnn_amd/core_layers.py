@@ -244,3 +244,316 @@ class HGCN(nn.Module):
         if self.use_knowledge:
             h = self.jk(hs)
         return self.layers[-1](h, edge_index, edge_type)
+
+
+# ------------------------------------------------------------------------------------------
+# ResGatedGraphConv (core/gnn.py:212-258) on the edge-gated aggregation kernels
+# ------------------------------------------------------------------------------------------
+class _GatedAggregate(torch.autograd.Function):
+    """S_i = sum_{(i,j)} sigmoid(a_i + b_j [+ c_e]) * h_j   (agnn_gated_*; c in COO edge order)."""
+
+    @staticmethod
+    def forward(ctx, fwd: Csr, bwd: Csr, a, b, h, c):
+        dev = _lib.require_gpu(a, b, h, c)
+        lib = _lib.load()
+        a, b, h = a.contiguous(), b.contiguous(), h.contiguous()
+        c = c.contiguous() if c is not None else None
+        n, H = a.shape
+        out = torch.empty_like(a)
+        g = _lib.Gated(fwd.rowptr.data_ptr(), fwd.col.data_ptr(), fwd.perm.data_ptr(), a.data_ptr(), b.data_ptr(),
+                       h.data_ptr(), _lib.ptr(c), a.stride(0), c.stride(0) if c is not None else 0, n, H)
+        _lib.check(lib.agnn_gated_fwd_f32(g, out.data_ptr(), out.stride(0), _lib.stream_ptr(dev)), "agnn_gated_fwd_f32")
+        ctx.csr = (fwd, bwd)
+        ctx.has_c = c is not None
+        ctx.save_for_backward(a, b, h, *([c] if c is not None else []))
+        return out
+
+    @staticmethod
+    def backward(ctx, ds):
+        fwd, bwd = ctx.csr
+        a, b, h, *rest = ctx.saved_tensors
+        c = rest[0] if ctx.has_c else None
+        dev = ds.device
+        lib = _lib.load()
+        ds = ds.contiguous()
+        n, H = a.shape
+        da = torch.empty_like(a)
+        db = torch.empty_like(b)
+        dh = torch.empty_like(h)
+        dc = torch.zeros_like(c) if c is not None else None
+        ldc = c.stride(0) if c is not None else 0
+        g1 = _lib.Gated(fwd.rowptr.data_ptr(), fwd.col.data_ptr(), fwd.perm.data_ptr(), a.data_ptr(), b.data_ptr(),
+                        h.data_ptr(), _lib.ptr(c), a.stride(0), ldc, n, H)
+        _lib.check(lib.agnn_gated_bwd_dst_f32(g1, ds.data_ptr(), ds.stride(0), da.data_ptr(), _lib.ptr(dc),
+                                              _lib.stream_ptr(dev)), "agnn_gated_bwd_dst_f32")
+        g2 = _lib.Gated(bwd.rowptr.data_ptr(), bwd.col.data_ptr(), bwd.perm.data_ptr(), a.data_ptr(), b.data_ptr(),
+                        h.data_ptr(), _lib.ptr(c), a.stride(0), ldc, b.shape[0], H)
+        _lib.check(lib.agnn_gated_bwd_src_f32(g2, ds.data_ptr(), ds.stride(0), db.data_ptr(), dh.data_ptr(),
+                                              _lib.stream_ptr(dev)), "agnn_gated_bwd_src_f32")
+        return None, None, da, db, dh, dc
+
+
+class ResGatedGraphConv(nn.Module):
+    """core/gnn.py:212-258.  out = 2 * W1 x + sum_j sigmoid(W3 x_i + W4 x_j [+ W5 e_ij]) * W2 x_j
+    (the reference scatters into `out=h1.clone()` and then adds h1 again, :256-257)."""
+
+    def __init__(self, in_features, out_features, bias=True, in_edge_features=None):
+        super().__init__()
+        self.W1 = nn.Linear(in_features, out_features, bias=bias)
+        self.W2 = nn.Linear(in_features, out_features, bias=bias)
+        self.W3 = nn.Linear(in_features, out_features, bias=bias)
+        self.W4 = nn.Linear(in_features, out_features, bias=bias)
+        self.in_edge_features = in_edge_features
+        if in_edge_features is not None:
+            self.W5 = nn.Linear(in_edge_features, out_features, bias=bias)
+        self.out_features = out_features
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for lin in (self.W1, self.W2, self.W3, self.W4):
+            _xavier_relu_(lin)
+        if self.in_edge_features is not None:
+            _xavier_relu_(self.W5)
+
+    def _projections(self, features, neigh_feats=None):
+        nf = features if neigh_feats is None else neigh_feats
+        W = torch.cat([self.W1.weight, self.W3.weight, self.W4.weight] + ([self.W2.weight] if neigh_feats is None else []), 0)
+        bias = None
+        if self.W1.bias is not None:
+            bias = torch.cat([self.W1.bias, self.W3.bias, self.W4.bias] + ([self.W2.bias] if neigh_feats is None else []), 0)
+        P = F.linear(features, W, bias)                     # one GEMM for W1, W3, W4 (and W2)
+        O = self.out_features
+        h1, a, b = P[:, :O], P[:, O:2 * O], P[:, 2 * O:3 * O]
+        h2 = P[:, 3 * O:4 * O] if neigh_feats is None else self.W2(nf)
+        return h1, a, b, h2
+
+    def forward_csr(self, features, fwd: Csr, bwd: Csr, c=None, neigh_feats=None):
+        h1, a, b, h2 = self._projections(features, neigh_feats)
+        (a4, O), (b4, _), (h4, _) = ops.pad4(a), ops.pad4(b), ops.pad4(h2)
+        c4 = ops.pad4(c)[0] if c is not None else None
+        s = _GatedAggregate.apply(fwd, bwd, a4, b4, h4, c4)
+        return 2.0 * h1 + (s[:, :O] if s.shape[1] != O else s)
+
+    def forward(self, features, edge_index, edge_features=None, neigh_feats=None):
+        _lib.require_gpu(features)
+        n = features.shape[0]
+        fwd, bwd = build_csr([SegSpec(edge_index[0], edge_index[1], n), SegSpec(edge_index[1], edge_index[0], n)])
+        c = None
+        if edge_features is not None and self.in_edge_features is not None:
+            c = self.W5(edge_features)
+        return self.forward_csr(features, fwd, bwd, c, neigh_feats)
+
+
+class _HeteroPerRelation(nn.Module):
+    """Shared forward of the in-tree hetero wrappers: one conv per relation slot, reduced over the R slots
+    (core/hgnn.py:58-63, :479-484).  One CSR build for all relations; SAGE convs take the fused path."""
+
+    def _run(self, x, edge_index, edge_type, edge_features=None):
+        _lib.require_gpu(x)
+        tix = typed_index(x.shape[0], edge_index, edge_type, self.etypes)
+        convs = [self.conv[k] for k in tix.names]
+        if all(isinstance(c, SageConvScatter) and c.in_edge_features is None for c in convs) and edge_features is None:
+            return HeteroSageConvLayer._fused(self, x, tix)
+        outs = []
+        for r, conv in enumerate(convs):
+            if isinstance(conv, ResGatedGraphConv):
+                c = None
+                if edge_features is not None and conv.in_edge_features is not None:
+                    c = conv.W5(edge_features)           # all edges; the kernel reads the rows of this relation's edges
+                outs.append(conv.forward_csr(x, tix.fwd[r], tix.bwd[r], c))
+            else:
+                raise NotImplementedError(f"{type(conv).__name__} inside a hetero wrapper is not on the HIP path")
+        st = torch.stack(outs, dim=0)
+        return st.mean(dim=0) if self.reduction == "mean" else st.sum(dim=0)
+
+
+class HeteroResGatedGraphConvLayer(_HeteroPerRelation):
+    """core/hgnn.py:26-63."""
+
+    def __init__(self, in_features, out_features, etypes, bias=True, reduction="mean"):
+        super().__init__()
+        self.out_features, self.in_features, self.etypes = out_features, in_features, etypes
+        self.reduction = _make_reduction(reduction)
+        self.conv = nn.ModuleDict({k: ResGatedGraphConv(in_features, out_features, bias=bias) for k in etypes.keys()})
+
+    def reset_parameters(self):
+        for c in self.conv.values():
+            c.reset_parameters()
+
+    def forward(self, x, edge_index, edge_type):
+        return self._run(x, edge_index, edge_type)
+
+
+class HeteroConv(_HeteroPerRelation):
+    """core/hgnn.py:435-484: wrap a conv class into a per-relation module with a reduction over relations."""
+
+    def __init__(self, in_features, out_features, etypes, in_edge_features=None, module=SageConvScatter, bias=True,
+                 reduction="mean"):
+        super().__init__()
+        self.out_features, self.in_features, self.etypes = out_features, in_features, etypes
+        self.reduction = _make_reduction(reduction)
+        self.conv = nn.ModuleDict({k: module(in_features, out_features, bias=bias, in_edge_features=in_edge_features)
+                                   for k in etypes.keys()})
+
+    def reset_parameters(self):
+        for c in self.conv.values():
+            c.reset_parameters()
+
+    def forward(self, x, edge_index, edge_type, edge_features=None):
+        return self._run(x, edge_index, edge_type, edge_features)
+
+
+class GATConvLayer(nn.Module):
+    """core/gnn.py:154-209.  The reference's softmax runs over the HEAD axis (its own remark at :205) and is
+    then averaged over heads, so every edge weight is 1/heads up to rounding; reproduced literally: per-edge
+    weights from the per-node scores, then a weighted gather-sum on the SpMM kernel."""
+
+    def __init__(self, in_features, out_features, num_heads=3, bias=True, dropout=0.3, negative_slope=0.2,
+                 in_edge_features=None):
+        super().__init__()
+        if in_edge_features is not None:
+            raise NotImplementedError("GATConvLayer(in_edge_features=...) is broken in the reference itself (attne never initialised)")
+        self.num_heads, self.in_features, self.out_features = num_heads, in_features, out_features
+        self.linear = nn.Linear(in_features, out_features, bias=bias)
+        self.el = nn.Linear(in_features, in_features * num_heads, bias=bias)
+        self.er = nn.Linear(in_features, in_features * num_heads, bias=bias)
+        self.attnl = nn.Parameter(torch.empty(1, num_heads, in_features))
+        self.attnr = nn.Parameter(torch.empty(1, num_heads, in_features))
+        self.negative_slope = negative_slope
+        self.attndrop = nn.Dropout(dropout)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        gain = nn.init.calculate_gain("relu")
+        for w in (self.linear.weight, self.el.weight, self.er.weight, self.attnl, self.attnr):
+            nn.init.xavier_normal_(w, gain=gain)
+        for lin in (self.linear, self.el, self.er):
+            if lin.bias is not None:
+                nn.init.constant_(lin.bias, 0.0)
+
+    def forward(self, features, edge_index, edge_features=None):
+        _lib.require_gpu(features)
+        n = features.shape[0]
+        s_l = (self.el(features).view(n, self.num_heads, self.in_features) * self.attnl).sum(-1)      # [N, heads]
+        s_r = (self.er(features).view(n, self.num_heads, self.in_features) * self.attnr).sum(-1)
+        e = F.leaky_relu(s_l[edge_index[0]] + s_r[edge_index[1]], self.negative_slope)
+        a = torch.softmax(self.attndrop(e), dim=1).mean(dim=1)                                          # [E]
+        h = self.linear(features)
+        hp, O = ops.pad4(h)
+        fwd, bwd = build_csr([SegSpec(edge_index[0], edge_index[1], n), SegSpec(edge_index[1], edge_index[0], n)])
+        spec = ops.AggSpec(fwd=[fwd], bwd=[bwd], src_id=[0], n_rows=n, mean=False, shared_slot=True,
+                           edge_weight=[a.detach()])
+        s = ops.aggregate(spec, [hp])
+        # d(out)/d(a) vanishes analytically (softmax over heads sums to one); keep `a` in the graph at zero cost
+        return h + (s[:, :O] if s.shape[1] != O else s) + 0.0 * a.sum()
+
+
+# ------------------------------------------------------------------------------------------
+# MetricalConvLayer (core/gnn.py:488-540) and the in-tree MetricalGNN (core/hgnn.py:323-433)
+# ------------------------------------------------------------------------------------------
+def _scatter_rows(src: torch.Tensor, dst_index: torch.Tensor, src_index: torch.Tensor, n_out: int) -> torch.Tensor:
+    """out[i] = sum_{e: dst_index[e] == i} src[src_index[e]]  (zero-initialised scatter_add of gathered rows)."""
+    fwd, bwd = build_csr([SegSpec(dst_index, src_index, n_out), SegSpec(src_index, dst_index, src.shape[0])])
+    sp, O = ops.pad4(src)
+    spec = ops.AggSpec(fwd=[fwd], bwd=[bwd], src_id=[0], n_rows=n_out, mean=False, shared_slot=True)
+    out = ops.aggregate(spec, [sp])
+    return out[:, :O] if out.shape[1] != O else out
+
+
+class MetricalConvLayer(nn.Module):
+    def __init__(self, in_dim, out_dim, activation=None, dropout=0.2, bias=True):
+        super().__init__()
+        self.input_dim, self.output_dim = in_dim, out_dim
+        self.activation = nn.Identity() if activation is None else activation
+        self.dropout = nn.Dropout(dropout)
+        self.normalize = nn.BatchNorm1d(out_dim)
+        self.neigh = nn.Linear(in_dim, in_dim, bias=bias)
+        self.conv_out = nn.Linear(4 * in_dim, out_dim, bias=bias)
+        self.seq = nn.GRU(in_dim, in_dim, batch_first=True, bias=bias, bidirectional=True)
+
+    def reset_parameters(self):
+        self.neigh.reset_parameters()
+        self.conv_out.reset_parameters()
+        self.seq.reset_parameters()
+
+    def forward(self, x_metrical, x, edge_index, lengths):
+        """edge_index[0] = note, edge_index[1] = beat/measure.  Returns (per-note output, per-beat state)."""
+        _lib.require_gpu(x_metrical, x)
+        from .gru import gru_forward
+        nm = x_metrical.size(0)
+        if lengths is None:
+            lengths = torch.tensor([nm], dtype=torch.long, device=x.device)
+        ragged = not bool(torch.all(lengths == lengths[0]))
+        h_scatter = _scatter_rows(self.neigh(x), edge_index[1], edge_index[0], nm)               # notes -> beats, :511
+        z_s = torch.cat((h_scatter, x_metrical), dim=-1)
+        if ragged:
+            sizes = torch.diff(lengths).tolist()
+            from torch.nn.utils.rnn import pad_sequence
+            z_s = pad_sequence(torch.split(z_s, sizes), batch_first=True)
+            h_metrical = pad_sequence(torch.split(h_scatter, sizes), batch_first=True)
+        else:
+            L0 = int(lengths[0])
+            h_metrical = h_scatter.view(-1, L0, h_scatter.shape[1])
+            z_s = z_s.view(-1, L0, z_s.shape[1])
+        h_seq = gru_forward(self.seq, h_metrical, self.training)
+        h = self.activation(self.conv_out(torch.cat([z_s, h_seq], dim=-1)))
+        h = self.dropout(self.normalize(h.transpose(1, 2))).transpose(1, 2)                        # BatchNorm over [B, C, T]
+        if ragged:
+            keep = torch.arange(h.shape[1], device=h.device).unsqueeze(0) < torch.tensor(sizes, device=h.device).unsqueeze(1)
+            h = h[keep].view(-1, h.shape[-1])
+        else:
+            h = h.reshape(-1, h.shape[-1])          # the reference's .view() raises here for > 1 sequence (gnn.py:538)
+        out = _scatter_rows(h, edge_index[0], edge_index[1], x.size(0))                            # beats -> notes, :539
+        return out, h
+
+
+class MetricalGNN(nn.Module):
+    """In-tree MetricalGNN (core/hgnn.py:323-433), metrical=True/False, SAGE conv blocks, no JK / reledge
+    (the reference's own jk branch builds JumpingKnowledge(n_layers=hidden_features), :340)."""
+
+    def __init__(self, input_features, hidden_features, output_features, etypes, num_layers=2, dropout=0.5,
+                 use_reledge=False, jk=False, in_edge_features=None, metrical=False, conv_block=SageConvScatter):
+        super().__init__()
+        if use_reledge or jk:
+            raise NotImplementedError("use_reledge / jk of the in-tree MetricalGNN are not on the HIP path")
+        self.dropout, self.num_layers, self.num_hidden = dropout, num_layers, hidden_features
+        self.use_metrical = metrical
+        self.convs = nn.ModuleList()
+        self.emb_beats = nn.Linear(input_features, hidden_features)
+        self.emb_measures = nn.Linear(input_features, hidden_features)
+        self.beat_convs, self.measure_convs, self.project_metrical = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        self.convs.append(HeteroConv(input_features, hidden_features, etypes=etypes, module=conv_block))
+        for _ in range(max(num_layers - 2, 0)):
+            self.convs.append(HeteroConv(hidden_features, hidden_features, etypes=etypes, module=conv_block))
+            if metrical:
+                self.beat_convs.append(MetricalConvLayer(hidden_features, hidden_features, activation=F.relu, dropout=dropout))
+                self.measure_convs.append(MetricalConvLayer(hidden_features, hidden_features, activation=F.relu, dropout=dropout))
+                self.project_metrical.append(nn.Linear(hidden_features * 3, hidden_features))
+        self.convs.append(HeteroConv(hidden_features, hidden_features, etypes=etypes, module=conv_block))
+        if metrical:
+            self.beat_convs.append(MetricalConvLayer(hidden_features, output_features, activation=F.relu, dropout=dropout))
+            self.measure_convs.append(MetricalConvLayer(hidden_features, output_features, activation=F.relu, dropout=dropout))
+            self.project_metrical.append(nn.Linear(output_features * 3, output_features))
+
+    def forward(self, x, edge_index, edge_type, beat_nodes, measure_nodes, beat_edges, measure_edges, rel_edge=None,
+                beat_lengths=None, measure_lengths=None, **kwargs):
+        _lib.require_gpu(x)
+        if self.use_metrical:
+            h_beat = _scatter_rows(self.emb_beats(x), beat_edges[1], beat_edges[0], beat_nodes.size(0))
+            h_measure = _scatter_rows(self.emb_measures(x), measure_edges[1], measure_edges[0], measure_nodes.size(0))
+
+        def metrical(k, h, h_beat, h_measure):
+            bc, h_beat = self.beat_convs[k](h_beat, h, beat_edges, beat_lengths)
+            mc, h_measure = self.measure_convs[k](h_measure, h, measure_edges, measure_lengths)
+            h = self.project_metrical[k](torch.cat([h, bc, mc], dim=-1))
+            return F.normalize(F.relu(h), p=2.0, dim=-1), h_beat, h_measure
+
+        h = x
+        for i in range(len(self.convs) - 1):
+            if i != 0 and self.use_metrical:
+                h, h_beat, h_measure = metrical(i - 1, h, h_beat, h_measure)
+            h = self.convs[i](h, edge_index, edge_type)
+            h = F.dropout(F.relu(F.normalize(h, p=2.0, dim=-1)), p=self.dropout, training=self.training)
+        if self.use_metrical:
+            h, h_beat, h_measure = metrical(len(self.beat_convs) - 1, h, h_beat, h_measure)
+        return self.convs[-1](h, edge_index, edge_type)

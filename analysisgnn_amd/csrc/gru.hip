@@ -10,7 +10,7 @@
 // an output row.  The input projection x W_ih^T (+b_ih) is a plain library GEMM done beforehand
 // for all steps at once.  The backward kernel walks the chain in reverse with W_hh^T in
 // registers and emits dGI / dHN; weight gradients are library GEMMs over those.
-// Exact fp32 (expf-based sigmoid/tanh), no atomics, bitwise reproducible.
+// fp32 throughout (v_exp/v_rcp gate functions, ~3 ulp), no atomics, bitwise reproducible run to run.
 #include "agnn_common.h"
 
 namespace {
@@ -35,8 +35,16 @@ __device__ __forceinline__ float group8_sum(float v) {
   v += dpp_half_mirror(v);
   return v;
 }
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return 2.f / (1.f + expf(-2.f * x)) - 1.f; }
+// Workgroup barrier that orders LDS traffic only.  `__syncthreads()` also waits for every outstanding
+// global load/store (s_waitcnt vmcnt(0)), which would put one HBM store round trip and the prefetch of
+// the next step's inputs on the critical path of EVERY time step of the recurrence.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Gate non-linearities on the hardware transcendental units: v_exp_f32 and v_rcp_f32 are each good to
+// ~1 ulp, so sigmoid is ~3 ulp (3e-7 relative) — far inside the 1e-4 parity budget — at 5 instructions
+// instead of ~40 for expf + IEEE division.  This block is on the serial critical path of every step.
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)) - 1.f; }
 
 // gi   [B, T, 2, 3*HH]  x W_ih^T + b_ih, gate order r,z,n (torch)
 // w_hh [2, 3*HH, HH], b_hh [2, 3*HH]
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
 #pragma unroll
     for (int gate = 0; gate < 3; ++gate) { gin[gate][0] = gnext[gate][0]; gin[gate][1] = gnext[gate][1]; }
     t = tn;
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -165,21 +173,32 @@ __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, co
     wt[0][j] = v.x; wt[1][j] = v.y;
   }
   float carry[2] = {0.f, 0.f};
+  // per-step operands (dy, saved gates, h_{t-1}) are fetched one step ahead
+  struct StepIn { float2 dyv, r2, z2, n2, q2, hp2; };
+  auto fetch = [&](int s_) {
+    StepIn o;
+    const int t_ = d ? s_ : T - 1 - s_;
+    const int tp_ = d ? t_ + 1 : t_ - 1;
+    const size_t bt_ = static_cast<size_t>(b) * T + t_;
+    o.dyv = *reinterpret_cast<const float2*>(dy + bt_ * 2 * HH + d * HH + u0);
+    const float* sv = saved + (bt_ * 2 + d) * 4 * HH + u0;
+    o.r2 = *reinterpret_cast<const float2*>(sv + 0 * HH);
+    o.z2 = *reinterpret_cast<const float2*>(sv + 1 * HH);
+    o.n2 = *reinterpret_cast<const float2*>(sv + 2 * HH);
+    o.q2 = *reinterpret_cast<const float2*>(sv + 3 * HH);
+    o.hp2 = make_float2(0.f, 0.f);
+    if (tp_ >= 0 && tp_ < T) o.hp2 = *reinterpret_cast<const float2*>(y + (static_cast<size_t>(b) * T + tp_) * 2 * HH + d * HH + u0);
+    return o;
+  };
+  StepIn nxt = fetch(0);
   for (int s = 0; s < T; ++s) {
     const int cur = s & 1;
     const int t = d ? s : T - 1 - s;            // reverse of the forward walk
-    const int tp = d ? t + 1 : t - 1;           // forward predecessor of t in this direction
     const size_t bt = static_cast<size_t>(b) * T + t;
-    const float2 dyv = *reinterpret_cast<const float2*>(dy + bt * 2 * HH + d * HH + u0);
-    const float* sv = saved + (bt * 2 + d) * 4 * HH + u0;
-    const float2 r2 = *reinterpret_cast<const float2*>(sv + 0 * HH);
-    const float2 z2 = *reinterpret_cast<const float2*>(sv + 1 * HH);
-    const float2 n2 = *reinterpret_cast<const float2*>(sv + 2 * HH);
-    const float2 q2 = *reinterpret_cast<const float2*>(sv + 3 * HH);
-    float2 hp2 = make_float2(0.f, 0.f);
-    if (tp >= 0 && tp < T) hp2 = *reinterpret_cast<const float2*>(y + (static_cast<size_t>(b) * T + tp) * 2 * HH + d * HH + u0);
-    const float dyq[2] = {dyv.x, dyv.y}, r[2] = {r2.x, r2.y}, z[2] = {z2.x, z2.y}, n[2] = {n2.x, n2.y},
-                hn[2] = {q2.x, q2.y}, hp[2] = {hp2.x, hp2.y};
+    const StepIn in = nxt;
+    if (s + 1 < T) nxt = fetch(s + 1);
+    const float dyq[2] = {in.dyv.x, in.dyv.y}, r[2] = {in.r2.x, in.r2.y}, z[2] = {in.z2.x, in.z2.y},
+                n[2] = {in.n2.x, in.n2.y}, hn[2] = {in.q2.x, in.q2.y}, hp[2] = {in.hp2.x, in.hp2.y};
     float dh[2], drp[2], dzp[2], dnp[2], dq[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -202,7 +221,7 @@ __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, co
       *reinterpret_cast<float2*>(&dgh[cur][1 * HH + u0]) = make_float2(dzp[0], dzp[1]);
       *reinterpret_cast<float2*>(&dgh[cur][2 * HH + u0]) = make_float2(dq[0], dq[1]);
     }
-    __syncthreads();
+    lds_barrier();
     float a[2] = {0.f, 0.f}, c[2] = {0.f, 0.f};
     const float4* gp = reinterpret_cast<const float4*>(&dgh[cur][JC * kc]);
 #pragma unroll

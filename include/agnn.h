@@ -15,6 +15,7 @@
  *                         models/analysis.py:580-586) and PyG `SAGEConv` mean aggregation under
  *                         `HeteroConv` (ref: models/cadence.py:147-159,174)
  *   agnn_gru_fwd/bwd_f32  `torch.nn.GRU` of the hybrid sequence branch (ref: models/cadence.py:249-285)
+ *   agnn_gated_*          `ResGatedGraphConv` edge gate + scatter (ref: core/gnn.py:246-257)
  *   agnn_multitask_ce_f32 the 21 per-task CrossEntropyLoss terms (ref: models/analysis.py:881-888)
  *   agnn_hgt_attn_*       PyG `HGTConv` message/softmax/aggregate, reached through graphmuse
  *                         `HybridHGT` (ref: models/analysis.py:445-453)
@@ -180,6 +181,34 @@ int agnn_hgt_attn_bwd_src_f32(const int32_t* rowptr, const int32_t* rowend, cons
                               int64_t ld_q, const float* dm, int64_t ld_dm, int64_t n_src_rows,
                               int32_t col_limit, int32_t H, int32_t heads, float* dk, float* dv,
                               int64_t ld_o, agnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Edge-gated aggregation of the in-tree ResGatedGraphConv (ref: models/core/gnn.py:243-258):
+ *     S_i = sum_{p in row i} sigmoid(a_i + b_col[p] [+ c_perm[p]]) * h_col[p]
+ * a, b, h are [*, ld] fp32 matrices (W3 x, W4 x, W2 x), c an optional per-edge [E, ld_c] term in COO order.
+ * fwd / bwd_dst take the CSR grouped by the aggregating row (a indexed by row; b, h by col);
+ * bwd_src takes the TRANSPOSED CSR (b, h indexed by row; a and dS by col).  Same a/b/h/c pointers in all calls.
+ *   bwd_dst: da_i = sum_e dS_i h_j z(1-z)   and, when dc != NULL, dc[perm[p]] = that summand
+ *   bwd_src: db_j = sum_e dS_i h_j z(1-z),  dh_j = sum_e z dS_i
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const int32_t* rowptr;  /* (device) [n_rows + 1] */
+  const int32_t* col;     /* (device) */
+  const int32_t* perm;    /* (device) COO position per CSR position (needed when c != NULL and in backward) */
+  const float* a;
+  const float* b;
+  const float* h;
+  const float* c;         /* (device) [n_edges, ld_c] or NULL */
+  int64_t ld, ld_c;
+  int64_t n_rows;
+  int32_t H;
+} agnn_gated_t;
+
+int agnn_gated_fwd_f32(const agnn_gated_t* g /* (host) */, float* out, int64_t ld_out, agnn_stream_t stream);
+int agnn_gated_bwd_dst_f32(const agnn_gated_t* g /* (host) */, const float* ds, int64_t ld_ds, float* da,
+                           float* dc, agnn_stream_t stream);
+int agnn_gated_bwd_src_f32(const agnn_gated_t* g /* (host) */, const float* ds, int64_t ld_ds, float* db,
+                           float* dh, agnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused multi-task cross entropy (label smoothing, ignore index) over column segments of one logits

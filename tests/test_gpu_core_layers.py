@@ -100,3 +100,102 @@ def test_hgcn(jk):
     I = _inputs(z, dev)
     out = m(I["x"], I["edge_index"], I["edge_type"])
     _check(z, m, out, I)
+
+
+@pytest.mark.parametrize("name", ["resgated", "resgated_edgefeat"])
+def test_res_gated(name):
+    from analysisgnn_amd.core_layers import ResGatedGraphConv
+    dev = torch.device("cuda:0")
+    z = load_golden(name)
+    ef = 5 if "in.edge_features" in z.files else None
+    m = _load(ResGatedGraphConv(8, 12, in_edge_features=ef), z, dev)
+    gk = ("x", "edge_features") if ef else ("x",)
+    I = _inputs(z, dev, gk)
+    out = m(I["x"], I["edge_index"], I.get("edge_features"))
+    _check(z, m, out, I, gk)
+
+
+def test_hetero_conv_resgated():
+    from analysisgnn_amd.core_layers import HeteroConv, ResGatedGraphConv
+    dev = torch.device("cuda:0")
+    z = load_golden("heteroconv_resgated")
+    rels = [str(r) for r in z["meta.rels"]]
+    m = _load(HeteroConv(8, 8, etypes={r: i for i, r in enumerate(rels)}, module=ResGatedGraphConv), z, dev)
+    I = _inputs(z, dev)
+    out = m(I["x"], I["edge_index"], I["edge_type"])
+    _check(z, m, out, I)
+
+
+def test_gat():
+    from analysisgnn_amd.core_layers import GATConvLayer
+    dev = torch.device("cuda:0")
+    z = load_golden("gat")
+    m = _load(GATConvLayer(8, 10, num_heads=3, dropout=0.0), z, dev)
+    I = _inputs(z, dev)
+    out = m(I["x"], I["edge_index"])
+    assert_close(out, z["out"], TOL, "out")
+    (out * torch.from_numpy(z["gout"]).to(dev)).sum().backward()
+    assert_close(I["x"].grad, z["grad.x"], TOL, "grad.x")
+    for n, p in m.named_parameters():          # attention-score gradients vanish analytically (softmax over heads)
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert_close(g, z[f"gw.{n}"], TOL, f"gw.{n}")
+
+
+def test_jumping_knowledge():
+    from analysisgnn_amd.core_layers import JumpingKnowledge
+    dev = torch.device("cuda:0")
+    z = load_golden("jk")
+    m = _load(JumpingKnowledge(n_hidden=8, n_layers=3), z, dev).train()
+    I = _inputs(z, dev, ("x0", "x1", "x2"))
+    out = m([I["x0"], I["x1"], I["x2"]])
+    _check(z, m, out, I, ("x0", "x1", "x2"))
+
+
+@pytest.mark.parametrize("tag", ["eq", "ragged"])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_intree_metrical_gnn(tag, mode):
+    """In-tree MetricalGNN(metrical=True): note->beat/measure scatter sums on the SpMM kernel, library GRU (hidden 8),
+    BatchNorm.  Train-mode gradients use the 1e-4 budget the fp32 BatchNorm backward needs (see test_oracle_intree);
+    eval mode checks the forward only (the library RNN refuses backward in eval mode, as cuDNN does)."""
+    from analysisgnn_amd.core_layers import MetricalGNN
+    dev = torch.device("cuda:0")
+    z = load_golden(f"metrical_{tag}_{mode}")
+    rels = [str(r) for r in z["meta.rels"]]
+    m = _load(MetricalGNN(8, 8, 8, etypes={r: i for i, r in enumerate(rels)}, num_layers=3, dropout=0.0, metrical=True), z, dev)
+    m.train(mode == "train")
+    I = _inputs(z, dev)
+    out = m(I["x"], I["edge_index"], I["edge_type"], I["beat_nodes"], I["measure_nodes"], I["beat_edges"],
+            I["measure_edges"], beat_lengths=I.get("beat_lengths"), measure_lengths=I.get("measure_lengths"))
+    assert_close(out, z["out"], TOL, "out")
+    if mode == "train":
+        (out * torch.from_numpy(z["gout"]).to(dev)).sum().backward()
+        assert_close(I["x"].grad, z["grad.x"], 3e-4, "grad.x")
+        for n, p in m.named_parameters():
+            assert_close(p.grad, z[f"gw.{n}"], 3e-4, f"gw.{n}")
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean"])
+@pytest.mark.parametrize("with_out", [True, False])
+def test_scatter_surface(reduce, with_out):
+    """analysisgnn_amd.scatter (torch_scatter-compatible names) vs the restated semantics (oracle/scatter_ref.py)."""
+    from analysisgnn_amd import scatter as S
+    from oracle import scatter_ref as R
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    n, e, w = 37, 140, 10
+    src = torch.randn(e, w, generator=g)
+    idx = torch.randint(0, n, (e,), generator=g)
+    out0 = torch.randn(n, w, generator=g) if with_out else None
+    sc, oc = src.clone().requires_grad_(True), (out0.clone().requires_grad_(True) if with_out else None)
+    ref = R.scatter(sc, idx, 0, out=(oc.clone() if with_out else None), dim_size=None if with_out else n, reduce=reduce)
+    sg = src.to(dev).requires_grad_(True)
+    og = out0.to(dev).requires_grad_(True) if with_out else None
+    got = S.scatter(sg, idx.to(dev), 0, out=og, dim_size=None if with_out else n, reduce=reduce)
+    assert_close(got, ref, 1e-5, "scatter")
+    go = torch.randn(ref.shape, generator=g)
+    (ref * go).sum().backward()
+    (got * go.to(dev)).sum().backward()
+    assert_close(sg.grad, sc.grad, 1e-5, "dsrc")
+    if with_out:
+        assert_close(og.grad, oc.grad, 1e-5, "dout")
+    assert S.scatter_add is S.scatter_sum and callable(S.scatter_mean)
