@@ -27,7 +27,8 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # AGNN_DIST_BACKEND=gloo lets several ranks share ONE GPU (rehearsing the N>1 flow on a 1-GPU box)
+            backend = os.environ.get("AGNN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -85,6 +86,6 @@ def max_over_ranks(x: float) -> float:
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return x
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    t = torch.tensor([x], dtype=torch.float64, device=dev)  # tiny scalar exchange, outside the timed region
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

@@ -108,6 +108,7 @@ def main():
     rank, local, world = dp.init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    local = local % torch.cuda.device_count()          # ranks may share a device only in the gloo rehearsal
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
