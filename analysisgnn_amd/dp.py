@@ -43,27 +43,55 @@ def shard_units(n_units: int, rank: int, world: int) -> List[int]:
 
 
 class FlatGradBuffer:
-    """All gradients of `params` in one contiguous fp32 buffer; `.grad` of each parameter is a view."""
+    """All gradients of `params` in one contiguous fp32 buffer (the all-reduce message).
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    Two modes:
+      * `views=True`  — `.grad` of each parameter is a view into the buffer, backward accumulates straight into
+        the message (no pack step; costs one tiny accumulate launch per parameter, fine when GPU-bound);
+      * `views=False` — autograd hands over fresh gradient tensors (no per-parameter accumulate launches, which
+        dominate when a step is launch-bound: ~130 parameters here) and `pack()` gathers them with ONE cat;
+        `.grad` then become views of the buffer so the optimizer sees the reduced / clipped values.
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], views: bool = True):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
         dev = self.params[0].device
-        n = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        o = 0
+        self.sizes = [p.numel() for p in self.params]
+        n = sum(self.sizes)
+        self.views = views
         for p in self.params:
             if p.dtype != torch.float32 or p.device != dev:
                 raise ValueError("FlatGradBuffer: fp32 parameters on one device expected")
-            p.grad = self.flat[o:o + p.numel()].view_as(p)
-            o += p.numel()
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        if views:
+            self._assign_views()
+
+    def _assign_views(self) -> None:
+        o = 0
+        for p, k in zip(self.params, self.sizes):
+            p.grad = self.flat[o:o + k].view_as(p)
+            o += k
 
     def zero(self) -> None:
-        self.flat.zero_()
+        if self.views:
+            self.flat.zero_()
+        else:
+            for p in self.params:
+                p.grad = None
+
+    def pack(self) -> None:
+        """views=False: gather the fresh gradients into the flat buffer (one launch)."""
+        if self.views:
+            return
+        parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
+        torch.cat(parts, out=self.flat)
+        self._assign_views()
 
     def all_reduce_mean(self, world: Optional[int] = None) -> None:
         """SUM over ranks then divide: the same mean DDP applies."""
+        self.pack()
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())
@@ -73,6 +101,42 @@ class FlatGradBuffer:
         total = torch.linalg.vector_norm(self.flat)
         self.flat.mul_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
         return total
+
+
+class FlatAdamW:
+    """AdamW over ONE flat parameter buffer (decoupled weight decay, bias correction — torch.optim.AdamW's update
+    rule, reference optimizer: models/analysis.py:1380-1381).  Parameters are re-pointed at views of the buffer,
+    gradients come from a `FlatGradBuffer`, so a step is a handful of whole-model elementwise launches instead of
+    per-parameter lists: ~5 M parameters in ~130 tensors make the foreach path launch-bound."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], grads: FlatGradBuffer, lr=1e-3, betas=(0.9, 0.999),
+                 eps=1e-8, weight_decay=1e-2):
+        self.params = [p for p in params if p.requires_grad]
+        assert [id(p) for p in self.params] == [id(p) for p in grads.params], "same parameter order as the gradient buffer"
+        self.grads = grads
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        dev = self.params[0].device
+        self.flat = torch.cat([p.detach().reshape(-1) for p in self.params]).to(dev)
+        o = 0
+        for p in self.params:
+            p.data = self.flat[o:o + p.numel()].view_as(p)
+            o += p.numel()
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self.t = 0
+
+    @torch.no_grad()
+    def step(self) -> None:
+        self.t += 1
+        b1, b2 = self.betas
+        g = self.grads.flat
+        self.flat.mul_(1.0 - self.lr * self.wd)
+        self.m.mul_(b1).add_(g, alpha=1.0 - b1)
+        self.v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+        bc1 = 1.0 - b1 ** self.t
+        bc2 = 1.0 - b2 ** self.t
+        denom = (self.v.sqrt() / (bc2 ** 0.5)).add_(self.eps)
+        self.flat.addcdiv_(self.m, denom, value=-self.lr / bc1)
 
 
 def barrier_and_sync() -> None:

@@ -162,6 +162,7 @@ class HeteroSAGEStack(nn.Module):
 
     def forward(self, x_dict, edge_index_dict, plan: TrimPlan, collect: Optional[list] = None):
         index = hetero_index(edge_index_dict, {k: int(v.shape[0]) for k, v in x_dict.items()})
+        self.last_index = index          # reused by the onset pooling that follows the encoder (models.py)
         for i, conv in enumerate(self.convs):
             keep = plan.n_keep[i]
             x_dict = {k: v for k, v in x_dict.items()}
@@ -177,6 +178,25 @@ class HeteroSAGEStack(nn.Module):
 # ------------------------------------------------------------------------------------------
 # hybrid (sequence) branch — persistent GRU kernels (gru.py) for hidden 128, library RNN otherwise
 # ------------------------------------------------------------------------------------------
+_LENGTHS_CACHE: Dict[tuple, tuple] = {}
+
+
+def _sequence_lengths(batch: torch.Tensor):
+    """Per-subgraph sequence lengths as a device tensor and a host list.  `bincount(...).tolist()` (what the
+    reference does, models/analysis.py:529-530) is a device->host sync that stalls the launch queue behind the
+    whole previous step; the result only depends on the batch-id tensor, so it is memoised on that tensor's
+    identity + version (a fresh batch tensor pays the sync once, like the reference)."""
+    key = (batch.data_ptr(), batch._version, batch.numel(), str(batch.device))
+    hit = _LENGTHS_CACHE.get(key)
+    if hit is None:
+        lengths = torch.bincount(batch)
+        hit = (lengths, lengths.tolist(), batch)          # keep `batch` alive so the data_ptr stays unique
+        if len(_LENGTHS_CACHE) >= 16:
+            _LENGTHS_CACHE.pop(next(iter(_LENGTHS_CACHE)))
+        _LENGTHS_CACHE[key] = hit
+    return hit[0], hit[1]
+
+
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -201,8 +221,7 @@ class _HybridMixin:
         self.cat_proj = nn.Linear(hidden_channels * 2, hidden_channels)
 
     def hybrid_forward(self, x, batch):
-        lengths = torch.bincount(batch)
-        lens = lengths.tolist()
+        lengths, lens = _sequence_lengths(batch)
         if len(set(lens)) == 1:                     # equal windows (the usual batch): a view, no padding
             y = x.view(len(lens), lens[0], x.shape[1])
             y = gru_forward(self.rnn, y, self.training)

@@ -218,6 +218,7 @@ class HeteroHGTStack(nn.Module):
 
     def forward(self, x_dict, edge_index_dict, plan: TrimPlan, collect: Optional[list] = None):
         index = hetero_index(edge_index_dict, {k: int(v.shape[0]) for k, v in x_dict.items()})
+        self.last_index = index
         for i, conv in enumerate(self.convs):
             x_dict = conv(x_dict, edge_index_dict, index, plan.n_keep[i], plan.e_keep[i])
             if i < self.num_layers - 1:

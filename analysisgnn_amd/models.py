@@ -16,14 +16,20 @@ from .heads import fused_head_logits
 from .graph import SegSpec, build_csr
 
 
-def onset_pool(x: torch.Tensor, onset_edges: torch.Tensor, batch_size: int) -> torch.Tensor:
+def onset_pool(x: torch.Tensor, onset_edges: torch.Tensor, batch_size: int, index=None) -> torch.Tensor:
     """analysis.py:580-587: onset edges with both ends < batch_size, self loops removed,
     x_pool_i = (x_i + sum_j x_j) / max(cnt_i, 1), returned as cat([x, x_pool]).
-    The two boolean-mask compactions become kernel-side predicates (col < limit, col != row)."""
+    The two boolean-mask compactions become kernel-side predicates (col < limit, col != row).  Messages flow from
+    edge row 1 to edge row 0, i.e. along the onset relation's by-SOURCE CSR — when the batch index is at hand
+    (`index`), that CSR and its transpose are reused instead of built again."""
     _lib.require_gpu(x, onset_edges)
     n = int(x.shape[0])
-    fwd, bwd = build_csr([SegSpec(onset_edges[0], onset_edges[1], n_rows=max(n, batch_size)),
-                          SegSpec(onset_edges[1], onset_edges[0], n_rows=max(n, batch_size))])
+    et = ("note", "onset", "note")
+    if index is not None and et in index.bwd and index.bwd[et].n_rows >= n:
+        fwd, bwd = index.bwd[et], index.fwd[et]
+    else:
+        fwd, bwd = build_csr([SegSpec(onset_edges[0], onset_edges[1], n_rows=max(n, batch_size)),
+                              SegSpec(onset_edges[1], onset_edges[0], n_rows=max(n, batch_size))])
     spec = ops.AggSpec(fwd=[fwd], bwd=[bwd], src_id=[0], n_rows=min(n, batch_size), mean=True, shared_slot=True,
                        skip_self=True, col_limit=batch_size)
     pooled = ops.aggregate(spec, [x], self_t=x)
@@ -79,7 +85,8 @@ class TorchAnalysisGNN(nn.Module):
         x = self.encoder(x_dict=h_dict, edge_index_dict=edge_index_dict, batch_dict=batch_dict,
                          batch_size=batch_size, neighbor_mask_node=neighbor_mask_node,
                          neighbor_mask_edge=neighbor_mask_edge, return_edge_index=False, edge_attr_dict=None)
-        x = onset_pool(x, edge_index_dict[("note", "onset", "note")], batch_size)
+        index = getattr(getattr(self.encoder, "gnn", None), "last_index", None)    # the CSR the encoder just built
+        x = onset_pool(x, edge_index_dict[("note", "onset", "note")], batch_size, index)
         return self.project_enc(x)
 
     def forward_clf(self, x, tasks=None):

@@ -99,12 +99,15 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--blas", default=None, choices=[None, "hipblaslt", "rocblas"], help="A/B only: torch's preferred BLAS library")
     args = ap.parse_args()
 
     from analysisgnn_amd import dp, graph, ops
     from analysisgnn_amd.models import TorchAnalysisGNN
     from analysisgnn_amd.synth import make_batch, torch_inputs
 
+    if args.blas:
+        torch.backends.cuda.preferred_blas_library("cublaslt" if args.blas == "hipblaslt" else "cublas")
     rank, local, world = dp.init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
@@ -119,8 +122,8 @@ def main():
     torch.manual_seed(0)                                            # identical replicas
     model = TorchAnalysisGNN(g.metadata(), IN_CH, H, OUT, TASK_DICT, LAYERS, dropout=0.3, use_jk=False,
                              encoder_type="hybridgnn").to(dev).train()
-    flat = dp.FlatGradBuffer(model.parameters())
-    opt = torch.optim.AdamW(model.parameters(), lr=5e-3, weight_decay=5e-3, foreach=True)
+    flat = dp.FlatGradBuffer(model.parameters(), views=False)
+    opt = dp.FlatAdamW(model.parameters(), flat, lr=5e-3, weight_decay=5e-3)     # analysis.py:1380-1381 hyper-parameters
     graph.index_cache_enabled = False                               # fresh batch every step: rebuild the CSR
 
     from analysisgnn_amd.heads import multitask_cross_entropy

@@ -98,3 +98,26 @@ def test_flat_buffer_views_and_clip():
     flat.zero()
     assert all(float(p.grad.abs().sum()) == 0 for p in m.parameters())
     assert dp.shard_units(7, 1, 3) == [1, 4]
+
+
+def test_flat_adamw_matches_torch_adamw():
+    """FlatAdamW (one flat buffer, a handful of launches) follows torch.optim.AdamW's update rule."""
+    import copy
+    from analysisgnn_amd import dp
+    torch.manual_seed(0)
+    a = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    b = copy.deepcopy(a)
+    ref = torch.optim.AdamW(a.parameters(), lr=5e-3, weight_decay=5e-3)
+    flat = dp.FlatGradBuffer(b.parameters(), views=False)
+    opt = dp.FlatAdamW(b.parameters(), flat, lr=5e-3, weight_decay=5e-3)
+    x = torch.randn(11, 5)
+    for _ in range(4):
+        ref.zero_grad()
+        a(x).pow(2).sum().backward()
+        ref.step()
+        flat.zero()
+        b(x).pow(2).sum().backward()
+        flat.all_reduce_mean()
+        opt.step()
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7)
