@@ -49,9 +49,9 @@ def loss_fn(logits, labels, feat):
     return loss
 
 
-def spmm_alg_bytes(graph, n_rel_expected):
+def spmm_alg_bytes(graph, n_rel_expected, H=H):
     """B_alg = sum_r [4(N_dst+1) + 4 E_r] + 4H (N_src_unique + R N_dst), forward aggregation."""
-    ets = [et for et in graph.edge_index if et[2] == "note"]
+    ets = [et for et in graph.edge_index if et[2] == "note" and et[0] == "note"]
     assert len(ets) == n_rel_expected
     n = graph.num_nodes["note"]
     idx = sum(4 * (n + 1) + 4 * graph.edge_index[et].shape[1] for et in ets)
@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"],
+                    help="c2 (default, the BASELINE metric): HybridGNN L=3 H=256; c3: HGT L=3 H=256 heads=4 with beat+measure "
+                         "nodes, 6 relation types; c5: MetricalGNN L=4 H=512, heads cadence/localkey/romanNumeral")
     ap.add_argument("--blas", default=None, choices=[None, "hipblaslt", "rocblas"], help="A/B only: torch's preferred BLAS library")
     args = ap.parse_args()
 
@@ -116,12 +119,24 @@ def main():
     dev = torch.device("cuda", local)
 
     # rank r owns subgraphs {r*32 .. r*32+31}: independent units, no data-path collective
-    g = make_batch(N_SUB, N_NOTES, first_seed=rank * N_SUB)
+    global TASK_DICT
+    enc, hid, layers = "hybridgnn", H, LAYERS
+    if args.workload == "c3":
+        g = make_batch(N_SUB, N_NOTES, first_seed=rank * N_SUB, add_beats=True, add_measures=True)
+        keep = [et for et in g.edge_types if et[0] == "note"]      # 4 note-note + note->beat + note->measure
+        g.edge_index = {et: g.edge_index[et] for et in keep}
+        enc = "hgt"
+    elif args.workload == "c5":
+        g = make_batch(N_SUB, N_NOTES, first_seed=rank * N_SUB)
+        enc, hid, layers = "metricalgnn", 512, 4
+        TASK_DICT = {"cadence": 4, "localkey": 50, "romanNumeral": 185}
+    else:
+        g = make_batch(N_SUB, N_NOTES, first_seed=rank * N_SUB)
     I = torch_inputs(g, IN_CH, dev, seed=rank)
     labels = make_labels(I["batch_size"], dev, 100 + rank)
     torch.manual_seed(0)                                            # identical replicas
-    model = TorchAnalysisGNN(g.metadata(), IN_CH, H, OUT, TASK_DICT, LAYERS, dropout=0.3, use_jk=False,
-                             encoder_type="hybridgnn").to(dev).train()
+    model = TorchAnalysisGNN(g.metadata(), IN_CH, hid, OUT, TASK_DICT, layers, dropout=0.3, use_jk=False,
+                             encoder_type=enc).to(dev).train()
     flat = dp.FlatGradBuffer(model.parameters(), views=False)
     opt = dp.FlatAdamW(model.parameters(), flat, lr=5e-3, weight_decay=5e-3)     # analysis.py:1380-1381 hyper-parameters
     graph.index_cache_enabled = False                               # fresh batch every step: rebuild the CSR
@@ -159,14 +174,18 @@ def main():
         # live timing of the dominant aggregation kernel: forward hetero SpMM, 4 relations -> [N, 4H]
         fwd = [e0.elapsed_time(e1) * 1e-3 for (tag, e0, e1, nrel, nrows, h, rs) in trace if tag == "fwd" and nrel == 4]
         bwd = [e0.elapsed_time(e1) * 1e-3 for (tag, e0, e1, nrel, nrows, h, rs) in trace if tag == "bwd" and nrel == 4]
-        b_alg, e_tot = spmm_alg_bytes(g, 4)
+        b_alg, e_tot = spmm_alg_bytes(g, 4, hid)
         t_fwd = sum(fwd) / max(len(fwd), 1)
         out = {
-            "metric": "subgraph-nodes/sec fwd+bwd, HybridGNN L=3 H=256", "value": nodes / dt,
+            "metric": {"c2": "subgraph-nodes/sec fwd+bwd, HybridGNN L=3 H=256", "c3": "subgraph-nodes/sec fwd+bwd, HGT L=3 H=256",
+                       "c5": "subgraph-nodes/sec fwd+bwd, MetricalGNN L=4 H=512"}[args.workload], "value": nodes / dt,
             "unit": "subgraph-nodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: HybridGNN L=3 H=256 out=128, 21 task heads, 32 subgraphs x 500 notes per GPU "
+            "config": {"workload": {"c3": "C3: HGT L=3 H=256 heads=4, note+beat+measure, 6 relation types; otherwise as C2 — ",
+                                    "c5": "C5: MetricalGNN L=4 H=512, heads cadence/localkey/romanNumeral; otherwise as C2 — ",
+                                    "c2": ""}[args.workload] +
+                                   "C2: HybridGNN L=3 H=256 out=128, 21 task heads, 32 subgraphs x 500 notes per GPU "
                                    "(4 note-note relations, %d edges), train step fwd+loss+bwd+allreduce+clip+AdamW, "
                                    "CSR rebuilt every step" % e_tot, "per_gpu_subgraphs": N_SUB, "notes_per_subgraph": N_NOTES,
                        "parallelism": f"dp{world}"},
