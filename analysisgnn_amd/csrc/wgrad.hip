@@ -1,0 +1,208 @@
+// Weight-gradient GEMM for the projection layers:  dW[out, in] = sum_n dY[n, out] * X[n, in]  (+ db[out] = sum_n dY[n, out])
+//
+// Every projection of the encoder sees N = (#subgraphs x 500) rows, so its weight gradient is a GEMM with a SMALL
+// output (256 x 256 ... 256 x 1024) and a HUGE reduction dimension (N = 16 000).  The library picks a
+// 32 x 32-tile kernel without a K split for that shape — a few dozen workgroups on a 256-CU chip: 88 us per
+// launch whatever the size, 19 launches per step (profiles/r01_c).  This kernel is built for the shape:
+//   * fp32-input MFMA (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD), no LDS at all — both operands are
+//     already "K-major": one MFMA k-step needs dY[n, 32 cols] and X[n, 32 cols] for two consecutive n, which is
+//     exactly one coalesced 8-byte-per-lane load of each (lane = column pair, lane half = n parity);
+//   * a 128 x 128 block tile, 4 waves in 2 x 2, each wave 64 x 64 = four accumulators; output rows/cols are taken
+//     with stride 2 inside a wave so the two floats a lane loads feed two different MFMA tiles without any shuffle;
+//   * N is cut into S slices so that (#tiles x S) ~ 2 workgroups per CU; each workgroup writes its partial tile to
+//     a slab and a second tiny kernel sums the S slabs in a fixed order (deterministic, no atomics);
+//   * the bias gradient rides along (column sums of the dY values already in registers).
+#include "agnn_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgArgs {
+  const float* dy;
+  const float* x;
+  int64_t ld_dy, ld_x;
+  int32_t n, out_f, in_f;
+  int32_t rows_per_slice;   // even
+  int32_t tiles_in;         // number of 128-wide tiles along `in`
+  float* slab;              // [S][out_pad][in_pad]
+  float* slab_b;            // [S][out_pad] or nullptr
+  int32_t out_pad, in_pad;
+};
+
+__global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = blockIdx.x, slice = blockIdx.y;
+  const int to = tile / a.tiles_in, ti = tile - to * a.tiles_in;
+  const int kk = lane >> 5, c32 = lane & 31;
+  const int ocol = to * 128 + wm * 64 + 2 * c32;     // this lane's two output-feature columns of dY
+  const int icol = ti * 128 + wn * 64 + 2 * c32;     // this lane's two input-feature columns of X
+  const bool o_ok = ocol < a.out_f;                  // widths are even: a float2 is inside or outside as a whole
+  const bool i_ok = icol < a.in_f;
+  const int r0 = slice * a.rows_per_slice;
+  int r1 = r0 + a.rows_per_slice;
+  if (r1 > a.n) r1 = a.n;
+
+  f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+  float bs0 = 0.f, bs1 = 0.f;
+  const float* dyp = a.dy + ocol;
+  const float* xp = a.x + icol;
+  // Rows are consumed two at a time (one MFMA k-step); CH k-steps are fetched together, one chunk ahead of the
+  // MFMAs that use them, so ~2*CH independent 8-byte loads per lane are in flight while 4*CH MFMAs (64 cycles
+  // each) run: with one k-step of prefetch the matrix pipe sat idle behind every HBM/L2 round trip.
+  constexpr int CH = 8;
+  float2 av[CH], bv[CH], an[CH], bn[CH];
+  auto fetch = [&](int base, float2* ao, float2* bo) {
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int n = base + 2 * u + kk;
+      ao[u] = make_float2(0.f, 0.f);
+      bo[u] = make_float2(0.f, 0.f);
+      if (n < r1) {
+        if (o_ok) ao[u] = *reinterpret_cast<const float2*>(dyp + static_cast<int64_t>(n) * a.ld_dy);
+        if (i_ok) bo[u] = *reinterpret_cast<const float2*>(xp + static_cast<int64_t>(n) * a.ld_x);
+      }
+    }
+  };
+  fetch(r0, av, bv);
+  for (int base = r0; base < r1; base += 2 * CH) {
+    if (base + 2 * CH < r1) fetch(base + 2 * CH, an, bn);
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].x, acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].y, acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].x, acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].y, acc11, 0, 0, 0);
+      bs0 += av[u].x;
+      bs1 += av[u].y;
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      av[u] = an[u];
+      bv[u] = bn[u];
+    }
+  }
+  // C/D layout of 32x32 MFMA: lane l, register r -> row i = (r&3) + 8*(r>>2) + 4*(l>>5), column j = l&31
+  float* slab = a.slab + (static_cast<int64_t>(slice) * a.out_pad) * a.in_pad;
+  const int ob = to * 128 + wm * 64, ib = ti * 128 + wn * 64;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * kk;
+    float* row0 = slab + static_cast<int64_t>(ob + 2 * i) * a.in_pad + ib + 2 * c32;          // output feature ob+2i   (tile c = 0)
+    float* row1 = row0 + a.in_pad;                                                            // output feature ob+2i+1 (tile c = 1)
+    *reinterpret_cast<float2*>(row0) = make_float2(acc00[r], acc01[r]);
+    *reinterpret_cast<float2*>(row1) = make_float2(acc10[r], acc11[r]);
+  }
+  if (a.slab_b != nullptr && wn == 0) {
+    bs0 += __shfl_xor(bs0, 32, 64);                  // the two lane halves hold the two n parities
+    bs1 += __shfl_xor(bs1, 32, 64);
+    if (kk == 0 && ti == 0)
+      *reinterpret_cast<float2*>(a.slab_b + static_cast<int64_t>(slice) * a.out_pad + ocol) = make_float2(bs0, bs1);
+  }
+}
+
+// dw[o][i] = sum_s slab[s][o][i] ;  db[o] = sum_s slab_b[s][o]   (fixed order: 8 interleaved partial sums, then a
+// fixed tree).  A block = 32 float2 columns x 8 slab groups, so the S slab reads of one output element are
+// spread over 8 threads with independent loads in flight instead of one thread walking S strided lines.
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slab, const float* __restrict__ slab_b, int S,
+                                                      int out_f, int in_f, int out_pad, int in_pad, float* __restrict__ dw,
+                                                      int64_t ld_dw, float* __restrict__ db) {
+  __shared__ float2 part[8][32];
+  const int col = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const int half_in = in_f >> 1;
+  const int64_t total = static_cast<int64_t>(out_f) * half_in;
+  const int64_t plane = static_cast<int64_t>(out_pad) * in_pad;
+  for (int64_t e0 = static_cast<int64_t>(blockIdx.x) * 32; e0 < total; e0 += static_cast<int64_t>(gridDim.x) * 32) {
+    const int64_t e = e0 + col;
+    float2 s = make_float2(0.f, 0.f);
+    int o = 0, i = 0;
+    if (e < total) {
+      o = static_cast<int>(e / half_in);
+      i = static_cast<int>(e - static_cast<int64_t>(o) * half_in) * 2;
+      const float* p = slab + static_cast<int64_t>(o) * in_pad + i;
+      for (int k = sg; k < S; k += 8) {
+        const float2 v = *reinterpret_cast<const float2*>(p + k * plane);
+        s.x += v.x;
+        s.y += v.y;
+      }
+    }
+    part[sg][col] = s;
+    __syncthreads();
+    if (sg == 0 && e < total) {
+      float2 t = part[0][col];
+#pragma unroll
+      for (int g = 1; g < 8; ++g) { t.x += part[g][col].x; t.y += part[g][col].y; }
+      *reinterpret_cast<float2*>(dw + static_cast<int64_t>(o) * ld_dw + i) = t;
+    }
+    __syncthreads();
+  }
+  if (db != nullptr) {
+    for (int64_t o = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; o < out_f; o += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+      float s = 0.f;
+      for (int k = 0; k < S; ++k) s += slab_b[static_cast<int64_t>(k) * out_pad + o];
+      db[o] = s;
+    }
+  }
+}
+
+struct Plan {
+  int tiles_out, tiles_in, S, rows_per_slice, out_pad, in_pad;
+};
+
+Plan make_plan(int64_t n, int out_f, int in_f) {
+  Plan p;
+  p.tiles_out = (out_f + 127) / 128;
+  p.tiles_in = (in_f + 127) / 128;
+  p.out_pad = p.tiles_out * 128;
+  p.in_pad = p.tiles_in * 128;
+  const int tiles = p.tiles_out * p.tiles_in;
+  int64_t S = (512 + tiles - 1) / tiles;            // ~2 workgroups per CU
+  const int64_t max_s = (n + 63) / 64;              // at least 64 rows per slice
+  if (S > max_s) S = max_s;
+  if (S > 64) S = 64;                               // slab traffic: S * out * in * 4 B written and read back
+  if (S < 1) S = 1;
+  int64_t rps = (n + S - 1) / S;
+  rps = (rps + 1) & ~int64_t{1};
+  p.rows_per_slice = static_cast<int>(rps);
+  p.S = static_cast<int>((n + rps - 1) / rps);
+  return p;
+}
+
+}  // namespace
+
+extern "C" size_t agnn_wgrad_workspace_bytes(int64_t n, int32_t out_f, int32_t in_f) {
+  if (n <= 0 || out_f <= 0 || in_f <= 0) return 0;
+  const Plan p = make_plan(n, out_f, in_f);
+  return (static_cast<size_t>(p.S) * p.out_pad * p.in_pad + static_cast<size_t>(p.S) * p.out_pad) * sizeof(float) + 256;
+}
+
+extern "C" int agnn_wgrad_f32(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, int64_t n, int32_t out_f,
+                              int32_t in_f, float* dw, int64_t ld_dw, float* db, void* workspace, size_t workspace_bytes,
+                              agnn_stream_t stream_) {
+  using namespace agnn;
+  if (n <= 0 || n >= (int64_t{1} << 31) || out_f <= 0 || in_f <= 0) return fail(AGNN_EINVAL, "wgrad: bad sizes n=%lld out=%d in=%d", (long long)n, out_f, in_f);
+  if ((out_f & 1) || (in_f & 1) || (ld_dy & 1) || (ld_x & 1) || (ld_dw & 1)) return fail(AGNN_EALIGN, "wgrad: widths and leading dimensions must be even");
+  if (!dy || !x || !dw || !workspace) return fail(AGNN_EINVAL, "wgrad: null argument");
+  if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dw) | reinterpret_cast<uintptr_t>(db)) & 7u)
+    return fail(AGNN_EALIGN, "wgrad: pointers must be 8-byte aligned");
+  if (ld_dy < out_f || ld_x < in_f || ld_dw < in_f) return fail(AGNN_EINVAL, "wgrad: leading dimension smaller than the width");
+  const size_t need = agnn_wgrad_workspace_bytes(n, out_f, in_f);
+  if (workspace_bytes < need) return fail(AGNN_ENOMEM, "wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
+  const Plan p = make_plan(n, out_f, in_f);
+  char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t{255});
+  float* slab = reinterpret_cast<float*>(ws);
+  float* slab_b = slab + static_cast<size_t>(p.S) * p.out_pad * p.in_pad;
+  WgArgs a{dy, x, ld_dy, ld_x, static_cast<int32_t>(n), out_f, in_f, p.rows_per_slice, p.tiles_in, slab,
+           db ? slab_b : nullptr, p.out_pad, p.in_pad};
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  hipLaunchKernelGGL(k_wgrad, dim3(p.tiles_out * p.tiles_in, p.S), dim3(256), 0, s, a);
+  if (int rc = check_launch("wgrad")) return rc;
+  const int64_t total = static_cast<int64_t>(out_f) * (in_f >> 1);
+  int blocks = static_cast<int>((total + 31) / 32);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks), dim3(256), 0, s, slab, db ? slab_b : nullptr, p.S, out_f, in_f, p.out_pad,
+                     p.in_pad, dw, ld_dw, db);
+  return check_launch("wgrad_reduce");
+}

@@ -80,11 +80,13 @@ class FlatGradBuffer:
         else:
             for p in self.params:
                 p.grad = None
+            self._packed = False
 
     def pack(self) -> None:
         """views=False: gather the fresh gradients into the flat buffer (one launch)."""
-        if self.views:
+        if self.views or getattr(self, "_packed", False):
             return
+        self._packed = True
         parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
         torch.cat(parts, out=self.flat)
         self._assign_views()
@@ -123,20 +125,22 @@ class FlatAdamW:
             o += p.numel()
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
-        self.t = 0
 
     @torch.no_grad()
     def step(self) -> None:
-        self.t += 1
+        """Graph-capturable: the step counter and the bias corrections live on the device."""
         b1, b2 = self.betas
         g = self.grads.flat
+        if not hasattr(self, "_t"):
+            self._t = torch.zeros((), dtype=torch.float32, device=self.flat.device)
+        self._t += 1.0
+        bc1 = 1.0 - (b1 ** self._t)
+        bc2 = 1.0 - (b2 ** self._t)
         self.flat.mul_(1.0 - self.lr * self.wd)
         self.m.mul_(b1).add_(g, alpha=1.0 - b1)
         self.v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
-        bc1 = 1.0 - b1 ** self.t
-        bc2 = 1.0 - b2 ** self.t
-        denom = (self.v.sqrt() / (bc2 ** 0.5)).add_(self.eps)
-        self.flat.addcdiv_(self.m, denom, value=-self.lr / bc1)
+        denom = (self.v.sqrt() / bc2.sqrt()).add_(self.eps)
+        self.flat.addcdiv_(self.m / bc1, denom, value=-self.lr)
 
 
 def barrier_and_sync() -> None:

@@ -31,6 +31,7 @@ import torch.nn.functional as F
 
 from . import _lib, ops
 from .gru import gru_forward
+from .linear import Linear, linear
 from .core_layers import JumpingKnowledge
 from .graph import HeteroIndex, hetero_index
 
@@ -143,7 +144,7 @@ class HeteroConv(nn.Module):
             W_l = torch.cat([c.lin_l.weight for c in convs], dim=1)                       # [out, R*H]
             b = sum(c.lin_l.bias for c in convs)
             W_r = sum(c.lin_r.weight for c in convs)
-            y = torch.addmm(F.linear(A, W_l, b), x_dict[d][:n], W_r.t())
+            y = linear(A, W_l, b) + linear(x_dict[d][:n], W_r)
             out[d] = y / len(ets) if self.aggr == "mean" else y
         return out
 
@@ -215,10 +216,10 @@ class _HybridMixin:
         self.rnn = nn.GRU(input_size=input_channels, hidden_size=hidden_channels // 2, num_layers=2,
                           batch_first=True, bidirectional=True, dropout=dropout)
         self.rnn_norm = nn.LayerNorm(hidden_channels)
-        self.rnn_mlp = nn.Sequential(nn.Linear(hidden_channels, hidden_channels), nn.ReLU(),
+        self.rnn_mlp = nn.Sequential(Linear(hidden_channels, hidden_channels), nn.ReLU(),
                                      nn.LayerNorm(hidden_channels), nn.Dropout(dropout),
-                                     nn.Linear(hidden_channels, hidden_channels))
-        self.cat_proj = nn.Linear(hidden_channels * 2, hidden_channels)
+                                     Linear(hidden_channels, hidden_channels))
+        self.cat_proj = Linear(hidden_channels * 2, hidden_channels)
 
     def hybrid_forward(self, x, batch):
         lengths, lens = _sequence_lengths(batch)
@@ -305,9 +306,9 @@ class MetricalGNN(nn.Module):
         self.use_jk = bool(use_jk)
         if self.use_jk:
             self.jk = JumpingKnowledge(hidden_channels, num_layers)
-        self.mlp = nn.Sequential(nn.Linear(hidden_channels, hidden_channels), nn.ReLU(),
+        self.mlp = nn.Sequential(Linear(hidden_channels, hidden_channels), nn.ReLU(),
                                  nn.LayerNorm(hidden_channels), nn.Dropout(dropout),
-                                 nn.Linear(hidden_channels, output_channels))
+                                 Linear(hidden_channels, output_channels))
 
     def forward(self, x_dict, edge_index_dict, neighbor_mask_node=None, neighbor_mask_edge=None, batch_dict=None,
                 batch_size=None, return_edge_index=False, edge_attr_dict=None):

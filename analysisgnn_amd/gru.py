@@ -11,6 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
+from .linear import weight_grad
 
 KERNEL_HIDDEN = 128
 
@@ -49,15 +50,17 @@ class _GRULayer(torch.autograd.Function):
         dgi2 = dgi.view(B * T, 6 * Hh)
         wf = w_ih.reshape(6 * Hh, I)
         dx = (dgi2 @ wf).view(B, T, I) if ctx.needs_input_grad[0] else None
-        dw_ih = (dgi2.t() @ x2).view(2, 3 * Hh, I)
-        db_ih = dgi2.sum(dim=0).view(2, 3 * Hh)
+        dw_ih, db_ih = weight_grad(dgi2, x2, True)
+        dw_ih, db_ih = dw_ih.view(2, 3 * Hh, I), db_ih.view(2, 3 * Hh)
         dgh = torch.cat([dgi[..., : 2 * Hh], dhn], dim=-1)                              # [B,T,2,3H]
         hp = torch.zeros((B, T, 2, Hh), dtype=torch.float32, device=dev)                 # h_{t-1} per direction
         if T > 1:
             hp[:, 1:, 0] = y[:, :-1, :Hh]
             hp[:, :-1, 1] = y[:, 1:, Hh:]
-        dw_hh = torch.einsum("btdj,btdk->djk", dgh, hp)
-        db_hh = dgh.sum(dim=(0, 1))
+        dgh2, hp2 = dgh.view(B * T, 6 * Hh), hp.view(B * T, 2 * Hh)
+        parts = [weight_grad(dgh2[:, d * 3 * Hh:(d + 1) * 3 * Hh], hp2[:, d * Hh:(d + 1) * Hh], True) for d in range(2)]
+        dw_hh = torch.stack([p[0] for p in parts])
+        db_hh = torch.stack([p[1] for p in parts])
         return dx, dw_ih, dw_hh, db_ih, db_hh
 
 

@@ -19,6 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
+from .linear import linear
 
 
 def fused_head_logits(clf_dict: nn.ModuleDict, x: torch.Tensor, tasks: Sequence[str]) -> Tuple[torch.Tensor, List[int]]:
@@ -28,13 +29,13 @@ def fused_head_logits(clf_dict: nn.ModuleDict, x: torch.Tensor, tasks: Sequence[
     h2 = mods[0][0].out_features
     W1 = torch.cat([m[0].weight for m in mods], dim=0)                    # [T*h2, o]
     b1 = torch.cat([m[0].bias for m in mods], dim=0)
-    a = F.relu(torch.addmm(b1, x, W1.t()))                                # [N, T*h2]
+    a = F.relu(linear(x, W1, b1))                                         # [N, T*h2]
     gamma = torch.stack([m[2].weight for m in mods])                      # [T, h2]
     beta = torch.stack([m[2].bias for m in mods])
     a = F.layer_norm(a.view(-1, T, h2), (h2,), None, None, mods[0][2].eps) * gamma + beta
     W2 = torch.block_diag(*[m[3].weight for m in mods])                   # [sum C, T*h2]
     b2 = torch.cat([m[3].bias for m in mods], dim=0)
-    logits = torch.addmm(b2, a.reshape(-1, T * h2), W2.t())
+    logits = linear(a.reshape(-1, T * h2), W2, b2)
     offs = [0]
     for m in mods:
         offs.append(offs[-1] + m[3].out_features)
@@ -73,5 +74,11 @@ class _MultiTaskCE(torch.autograd.Function):
 def multitask_cross_entropy(logits: torch.Tensor, offs: Sequence[int], labels: torch.Tensor, label_smoothing: float = 0.1,
                             ignore_index: int = -1) -> torch.Tensor:
     """Per-task mean losses [T] for side-by-side logits [N, sum C]; labels int64 [T, N]."""
-    offs_t = torch.tensor(list(offs), dtype=torch.int32, device=logits.device)
+    key = (tuple(offs), str(logits.device))
+    offs_t = _OFFS_CACHE.get(key)
+    if offs_t is None:                       # host -> device once per head layout (keeps the step graph-capturable)
+        offs_t = _OFFS_CACHE[key] = torch.tensor(list(offs), dtype=torch.int32, device=logits.device)
     return _MultiTaskCE.apply(logits, labels, offs_t, label_smoothing, ignore_index)
+
+
+_OFFS_CACHE: Dict[tuple, torch.Tensor] = {}

@@ -86,10 +86,19 @@ class _HGTAttention(torch.autograd.Function):
         lib = _lib.load()
         n, H, heads = spec.n_rows, q.shape[1], spec.heads
         dm = _mat(dm)
-        dq = torch.zeros_like(q)
-        alpha = [torch.zeros((max(spec.n_edges[r], 1), heads), dtype=torch.float32, device=dev) for r in range(R)]
-        gs = [torch.zeros_like(a) for a in alpha]
-        tdot = [torch.zeros_like(a) for a in alpha]
+        dq = torch.empty_like(q) if n == q.shape[0] else torch.zeros_like(q)
+        # per-edge arrays of all relations in three allocations; only tdot is summed over ALL edges (trimmed ones
+        # included), so only it needs zeros — alpha / gs are read back solely at positions the kernel wrote
+        ne = [max(spec.n_edges[r], 1) for r in range(R)]
+        offs = [0]
+        for k_ in ne:
+            offs.append(offs[-1] + k_)
+        a_all = torch.empty((offs[-1], heads), dtype=torch.float32, device=dev)
+        g_all = torch.empty((offs[-1], heads), dtype=torch.float32, device=dev)
+        t_all = torch.zeros((offs[-1], heads), dtype=torch.float32, device=dev)
+        alpha = [a_all[offs[r]:offs[r + 1]] for r in range(R)]
+        gs = [g_all[offs[r]:offs[r + 1]] for r in range(R)]
+        tdot = [t_all[offs[r]:offs[r + 1]] for r in range(R)]
         rels = (_lib.HgtRel * max(R, 1))()
         keep = []
         for r in range(R):
@@ -146,6 +155,16 @@ class _RelWeight(nn.Module):
         self.weight = nn.Parameter(torch.empty(num_types, dim, dim).uniform_(-bound, bound))
 
 
+_SEL_CACHE: Dict[tuple, torch.Tensor] = {}
+
+
+def _index_tensor(ids: tuple, device) -> torch.Tensor:
+    key = (ids, str(device))
+    if key not in _SEL_CACHE:
+        _SEL_CACHE[key] = torch.tensor(list(ids), device=device)
+    return _SEL_CACHE[key]
+
+
 class HGTConv(nn.Module):
     def __init__(self, in_channels: int, out_channels: int, metadata, heads: int = 1):
         super().__init__()
@@ -179,6 +198,29 @@ class HGTConv(nn.Module):
             s, _, d = et
             if et in index.fwd and s in x_dict and d in x_dict:
                 by_dst.setdefault(d, []).append((e_idx, et))
+        # Relation transforms k' = k A_r^k, v' = v A_r^v: the per-(relation, head) D x D matrices of all relations that
+        # leave one source type are laid out as ONE block-diagonal [H, R_s*H] weight, so every source type needs one
+        # GEMM for K' and one for V' (and two well-shaped GEMMs for their weight gradients) instead of 2*R_s batched
+        # 64x64 GEMMs whose weight gradients have K = N and a 64 x 64 output.
+        by_src: Dict[str, List[int]] = {}
+        used = [e_idx for rels in by_dst.values() for e_idx, _ in rels]
+        for e_idx in used:
+            by_src.setdefault(self.edge_types[e_idx][0], []).append(e_idx)
+        kv_of: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+        ar = torch.arange(heads, device=next(iter(x_dict.values())).device)
+        for s, e_list in by_src.items():
+            Rs = len(e_list)
+            sel = _index_tensor(tuple(e_list), ar.device)
+
+            def big(weight):
+                w4 = weight.view(len(self.edge_types), heads, D, D).index_select(0, sel)      # [Rs, heads, D, D]
+                wb = w4.new_zeros(heads, D, Rs, heads, D)
+                wb[ar, :, :, ar, :] = w4.permute(1, 2, 0, 3)                                # block (h, r): A_r,h
+                return wb.view(H, Rs * H)
+            k_all = k[s] @ big(self.k_rel.weight)                                           # [N_s, Rs*H]
+            v_all = v[s] @ big(self.v_rel.weight)
+            for i, e_idx in enumerate(e_list):
+                kv_of[e_idx] = (k_all[:, i * H:(i + 1) * H], v_all[:, i * H:(i + 1) * H])
         out = {}
         for t, x in x_dict.items():
             n = n_of[t]
@@ -186,13 +228,7 @@ class HGTConv(nn.Module):
             if rels and n > 0:
                 kv, ps = [], []
                 for e_idx, et in rels:
-                    s = et[0]
-                    Wk = self.k_rel.weight[e_idx * heads:(e_idx + 1) * heads]
-                    Wv = self.v_rel.weight[e_idx * heads:(e_idx + 1) * heads]
-                    ns = k[s].shape[0]
-                    k2 = torch.bmm(k[s].reshape(ns, heads, D).transpose(0, 1), Wk).transpose(0, 1).reshape(ns, H)
-                    v2 = torch.bmm(v[s].reshape(ns, heads, D).transpose(0, 1), Wv).transpose(0, 1).reshape(ns, H)
-                    kv += [k2, v2]
+                    kv += list(kv_of[e_idx])
                     ps.append(self.p_rel["__".join(et)].reshape(heads) / math.sqrt(D))
                 spec = _AttnSpec(fwd=[index.fwd[et] for _, et in rels], bwd=[index.bwd[et] for _, et in rels], n_rows=n,
                                  heads=heads, n_edges=[index.num_edges[et] for _, et in rels],

@@ -13,6 +13,7 @@ import torch.nn as nn
 from . import _lib, ops
 from .encoders import HybridGNN, MetricalGNN
 from .heads import fused_head_logits
+from .linear import Linear
 from .graph import SegSpec, build_csr
 
 
@@ -39,7 +40,7 @@ def onset_pool(x: torch.Tensor, onset_edges: torch.Tensor, batch_size: int, inde
 
 
 def _input_mlp(i, h, dropout):
-    return nn.Sequential(nn.Linear(i, h), nn.ReLU(), nn.LayerNorm(h), nn.Dropout(dropout), nn.Linear(h, h))
+    return nn.Sequential(Linear(i, h), nn.ReLU(), nn.LayerNorm(h), nn.Dropout(dropout), Linear(h, h))
 
 
 class TorchAnalysisGNN(nn.Module):
@@ -70,8 +71,8 @@ class TorchAnalysisGNN(nn.Module):
             raise ValueError(encoder_type)
         h, o = hidden_channels, out_channels
         self.project_enc = nn.Sequential(
-            nn.LayerNorm(2 * h), nn.Linear(2 * h, h), nn.ReLU(), nn.LayerNorm(h), nn.Dropout(dropout),
-            nn.Linear(h, o), nn.ReLU(), nn.LayerNorm(o), nn.Dropout(dropout), nn.Linear(o, o))
+            nn.LayerNorm(2 * h), Linear(2 * h, h), nn.ReLU(), nn.LayerNorm(h), nn.Dropout(dropout),
+            Linear(h, o), nn.ReLU(), nn.LayerNorm(o), nn.Dropout(dropout), Linear(o, o))
         self.clf_dict = nn.ModuleDict({
             t: nn.Sequential(nn.Linear(o, o // 2), nn.ReLU(), nn.LayerNorm(o // 2), nn.Linear(o // 2, c))
             for t, c in task_dict.items()})

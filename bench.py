@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"],
                     help="c2 (default, the BASELINE metric): HybridGNN L=3 H=256; c3: HGT L=3 H=256 heads=4 with beat+measure "
                          "nodes, 6 relation types; c5: MetricalGNN L=4 H=512, heads cadence/localkey/romanNumeral")
+    ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying hipGraphs")
+    ap.add_argument("--library-wgrad", action="store_true", help="A/B only: weight gradients through the library GEMM")
     ap.add_argument("--blas", default=None, choices=[None, "hipblaslt", "rocblas"], help="A/B only: torch's preferred BLAS library")
     args = ap.parse_args()
 
@@ -109,6 +111,9 @@ def main():
     from analysisgnn_amd.models import TorchAnalysisGNN
     from analysisgnn_amd.synth import make_batch, torch_inputs
 
+    if args.library_wgrad:
+        from analysisgnn_amd import linear as _lin
+        _lin.ENABLED = False
     if args.blas:
         torch.backends.cuda.preferred_blas_library("cublaslt" if args.blas == "hipblaslt" else "cublas")
     rank, local, world = dp.init_distributed()
@@ -144,30 +149,84 @@ def main():
     from analysisgnn_amd.heads import multitask_cross_entropy
     label_mat = torch.stack([labels[t] for t in TASK_DICT])             # [T, N]
 
-    def step():
+    def fwd_bwd():
         flat.zero()
         x = model.encode(I["pitch_spelling"], I["key_signature"], I["x_dict"], I["edge_index_dict"], I["batch_dict"],
                          I["batch_size"], None, None)
         logits, offs, _ = model.forward_clf_fused(x)
         loss = 0.1 * x.pow(2).mean() + multitask_cross_entropy(logits, offs, label_mat, 0.1, -1).sum()
         loss.backward()
-        flat.all_reduce_mean()
+        flat.pack()
+        return loss
+
+    def update():
         flat.clip_norm_(1.0)
         opt.step()
+
+    # The whole step is ~450 launches; issued one by one from Python they cost more host time than GPU time, so
+    # the two launch sequences (forward+backward+gradient gather; clip+AdamW) are captured ONCE into hipGraphs and
+    # replayed, with the gradient all-reduce between them.  The batch tensors are static buffers that a loader would
+    # refill; the graphs still rebuild the CSR from the COO edge lists on every replay.
+    graphs = None
+    loss_ref = [None]
+    if not args.no_graph:
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    fwd_bwd(); flat.all_reduce_mean(); update()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                loss_ref[0] = fwd_bwd()
+            with torch.cuda.graph(g2):
+                update()
+            graphs = (g1, g2)
+        except Exception as e:                                  # capture refused: run eagerly, say so in the JSON
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graphs = None
+            torch.cuda.synchronize(dev)
+
+    def step():
+        if graphs is not None:
+            graphs[0].replay()
+            flat.all_reduce_mean()
+            graphs[1].replay()
+            return loss_ref[0]
+        loss = fwd_bwd()
+        flat.all_reduce_mean()
+        update()
         return loss
 
     for _ in range(args.warmup):
         step()
     dp.barrier_and_sync()
-    ops.SPMM_TRACE = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     dp.barrier_and_sync()
     dt = time.perf_counter() - t0
-    trace, ops.SPMM_TRACE = ops.SPMM_TRACE, None
     dt = dp.max_over_ranks(dt)
     assert torch.isfinite(loss).item(), "loss diverged"
+    # live timing of the dominant aggregation kernel (HIP events on the launch stream): the step's own launches when
+    # running eagerly are replayed from a graph, so the same three forward + three backward aggregation launches of a
+    # step are issued here once more, 20 times, on the same tensors
+    ops.SPMM_TRACE = []
+    from analysisgnn_amd.graph import HeteroIndex
+    hix = HeteroIndex(I["edge_index_dict"], {k: int(v.shape[0]) for k, v in I["x_dict"].items()})
+    ets4 = [et for et in hix.edge_types if et[0] == "note" and et[2] == "note"]
+    spec4 = ops.AggSpec(fwd=[hix.fwd[e] for e in ets4], bwd=[hix.bwd[e] for e in ets4], src_id=[0] * len(ets4),
+                        n_rows=I["batch_size"], mean=True, shared_slot=False)
+    xs = torch.randn(I["batch_size"], hid, device=dev, requires_grad=True)
+    gsp = torch.randn(I["batch_size"], hid * len(ets4), device=dev)
+    for _ in range(20):
+        for _ in range(3):
+            xs.grad = None
+            ops.aggregate(spec4, [xs]).backward(gsp)
+    torch.cuda.synchronize(dev)
+    trace, ops.SPMM_TRACE = ops.SPMM_TRACE, None
 
     if rank == 0:
         nodes = I["batch_size"] * world * args.steps
@@ -187,7 +246,7 @@ def main():
                                     "c2": ""}[args.workload] +
                                    "C2: HybridGNN L=3 H=256 out=128, 21 task heads, 32 subgraphs x 500 notes per GPU "
                                    "(4 note-note relations, %d edges), train step fwd+loss+bwd+allreduce+clip+AdamW, "
-                                   "CSR rebuilt every step" % e_tot, "per_gpu_subgraphs": N_SUB, "notes_per_subgraph": N_NOTES,
+                                   "CSR rebuilt every step; " % e_tot + ("hipGraph replay" if graphs is not None else "eager launches"), "per_gpu_subgraphs": N_SUB, "notes_per_subgraph": N_NOTES,
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "kernel": "k_spmm_fast<1,false,false,false> forward hetero-SpMM (R=4, N=16000, H=256 -> [N,4H])",
                          "achieved": b_alg / t_fwd / 1e9 if t_fwd > 0 else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

@@ -16,6 +16,7 @@
  *                         `HeteroConv` (ref: models/cadence.py:147-159,174)
  *   agnn_gru_fwd/bwd_f32  `torch.nn.GRU` of the hybrid sequence branch (ref: models/cadence.py:249-285)
  *   agnn_gated_*          `ResGatedGraphConv` edge gate + scatter (ref: core/gnn.py:246-257)
+ *   agnn_wgrad_f32        weight/bias gradients of the dense projections (fp32 MFMA, split over N)
  *   agnn_multitask_ce_f32 the 21 per-task CrossEntropyLoss terms (ref: models/analysis.py:881-888)
  *   agnn_hgt_attn_*       PyG `HGTConv` message/softmax/aggregate, reached through graphmuse
  *                         `HybridHGT` (ref: models/analysis.py:445-453)
@@ -209,6 +210,19 @@ int agnn_gated_bwd_dst_f32(const agnn_gated_t* g /* (host) */, const float* ds, 
                            float* dc, agnn_stream_t stream);
 int agnn_gated_bwd_src_f32(const agnn_gated_t* g /* (host) */, const float* ds, int64_t ld_ds, float* db,
                            float* dh, agnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight-gradient GEMM of a projection layer y = x W^T + b over N rows (N large, out/in small):
+ *     dw[out, in] = sum_n dy[n, out] * x[n, in]        db[out] = sum_n dy[n, out]   (db may be NULL)
+ * fp32-input MFMA, split along N into slabs in `workspace` (agnn_wgrad_workspace_bytes), summed in a fixed
+ * order.  Replaces the backward of the `nn.Linear` / PyG `lin_l`, `lin_r` projections on the path
+ * (ref: models/analysis.py:429-443,474-485; models/cadence.py:147-159).  out, in and all leading dimensions
+ * must be even, pointers 8-byte aligned.
+ * ------------------------------------------------------------------------------------------ */
+size_t agnn_wgrad_workspace_bytes(int64_t n, int32_t out_f, int32_t in_f);
+int agnn_wgrad_f32(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, int64_t n, int32_t out_f,
+                   int32_t in_f, float* dw, int64_t ld_dw, float* db, void* workspace, size_t workspace_bytes,
+                   agnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused multi-task cross entropy (label smoothing, ignore index) over column segments of one logits

@@ -120,4 +120,4 @@ def test_flat_adamw_matches_torch_adamw():
         flat.all_reduce_mean()
         opt.step()
     for p, q in zip(a.parameters(), b.parameters()):
-        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7)
+        assert torch.allclose(p, q, rtol=1e-4, atol=1e-6)
