@@ -210,29 +210,44 @@ def main():
     dt = time.perf_counter() - t0
     dt = dp.max_over_ranks(dt)
     assert torch.isfinite(loss).item(), "loss diverged"
-    # live timing of the dominant aggregation kernel (HIP events on the launch stream): the step's own launches when
-    # running eagerly are replayed from a graph, so the same three forward + three backward aggregation launches of a
-    # step are issued here once more, 20 times, on the same tensors
-    ops.SPMM_TRACE = []
+    # Live timing of the dominant aggregation kernel.  Inside the timed region the launches are replayed from a
+    # hipGraph, where single kernels cannot be bracketed by events; and an event pair around ONE eager launch mostly
+    # measures the ~8 us of event / dispatch overhead.  So the same launch (this step's forward hetero-SpMM: same CSR,
+    # same shapes) is captured REP times back to back into a small graph and HIP events bracket each replay on the
+    # launch stream: average launch duration = replay time / REP (kernel + the ~1.5 us kernel-to-kernel boundary).
     from analysisgnn_amd.graph import HeteroIndex
     hix = HeteroIndex(I["edge_index_dict"], {k: int(v.shape[0]) for k, v in I["x_dict"].items()})
     ets4 = [et for et in hix.edge_types if et[0] == "note" and et[2] == "note"]
     spec4 = ops.AggSpec(fwd=[hix.fwd[e] for e in ets4], bwd=[hix.bwd[e] for e in ets4], src_id=[0] * len(ets4),
                         n_rows=I["batch_size"], mean=True, shared_slot=False)
-    xs = torch.randn(I["batch_size"], hid, device=dev, requires_grad=True)
-    gsp = torch.randn(I["batch_size"], hid * len(ets4), device=dev)
-    for _ in range(20):
-        for _ in range(3):
-            xs.grad = None
-            ops.aggregate(spec4, [xs]).backward(gsp)
-    torch.cuda.synchronize(dev)
-    trace, ops.SPMM_TRACE = ops.SPMM_TRACE, None
+    xs = torch.randn(I["batch_size"], hid, device=dev)
+    REP = 10
 
+    def timed(fn, use_graph=True):
+        fn(); torch.cuda.synchronize(dev)
+        run, per = fn, 1
+        if use_graph:
+            try:
+                sgraph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(sgraph):
+                    for _ in range(REP):
+                        fn()
+                run, per = sgraph.replay, REP
+            except Exception:
+                run, per = fn, 1
+        ts = []
+        for _ in range(12):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); run(); e1.record(); e1.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e-3 / per)
+        return ts[2:]
+
+    with torch.no_grad():
+        fwd = timed(lambda: ops.aggregate(spec4, [xs]))
+    trace = None
     if rank == 0:
         nodes = I["batch_size"] * world * args.steps
         # live timing of the dominant aggregation kernel: forward hetero SpMM, 4 relations -> [N, 4H]
-        fwd = [e0.elapsed_time(e1) * 1e-3 for (tag, e0, e1, nrel, nrows, h, rs) in trace if tag == "fwd" and nrel == 4]
-        bwd = [e0.elapsed_time(e1) * 1e-3 for (tag, e0, e1, nrel, nrows, h, rs) in trace if tag == "bwd" and nrel == 4]
         b_alg, e_tot = spmm_alg_bytes(g, 4, hid)
         t_fwd = sum(fwd) / max(len(fwd), 1)
         out = {
@@ -250,9 +265,11 @@ def main():
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "kernel": "k_spmm_fast<1,false,false,false> forward hetero-SpMM (R=4, N=16000, H=256 -> [N,4H])",
                          "achieved": b_alg / t_fwd / 1e9 if t_fwd > 0 else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": (b_alg / t_fwd) / HBM_PEAK if t_fwd > 0 else None, "traffic": None,
-                         "alg_bytes_per_launch": b_alg, "avg_us": t_fwd * 1e6, "launches": len(fwd),
-                         "bwd_avg_us": (sum(bwd) / max(len(bwd), 1)) * 1e6},
+                         "frac": (b_alg / t_fwd) / HBM_PEAK if t_fwd > 0 else None,
+                         # HBM bytes per launch from rocprofv3 PMC passes of this kernel at this shape (FETCH_SIZE x2 gfx950
+                         # correction + WRITE_SIZE, separate passes): profiles/r01_spmm_kernel_study.md — not re-collected per run
+                         "traffic": 83.5e6 if args.workload == "c2" else None,
+                         "alg_bytes_per_launch": b_alg, "avg_us": t_fwd * 1e6, "launches": len(fwd) * REP, "timing": "HIP events around hipGraph replays of 10 back-to-back launches"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
