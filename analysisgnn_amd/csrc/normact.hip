@@ -1,0 +1,257 @@
+// Fused  [ReLU ->] LayerNorm [-> ReLU] [-> dropout]  over the rows of a [N, H] fp32 matrix, forward and backward.
+//
+// The reference's wrapper and the encoder spec interleave these element-wise ops between every projection
+// (analysisgnn/models/analysis.py:429-443, :474-485; models/cadence.py:252-259): as separate library launches they
+// are ~60 launches and ~1.3 ms of the 7.7 ms step (profiles/r01_g), each reading and writing the full activation.
+// Here one wavefront owns one row (a lane owns 4 floats of every 256-float chunk): the row is read once, mean /
+// variance are butterfly reductions in registers, and the result is written once.  Nothing but the input, the
+// row statistics and the (seed, step, call) triple is kept for backward: ReLU masks are recomputed from the saved
+// input, the dropout mask from the counter-based generator (Philox-4x32-10 keyed by the seed, counter = element
+// index / call id / training step read from a device buffer, so a captured hipGraph draws fresh masks per replay).
+// gamma / beta gradients: each wave accumulates its rows in registers and writes one partial row; a second small
+// kernel sums the partials in a fixed order (no atomics, reproducible).  HBM-bound.
+#include <cmath>
+
+#include "agnn_common.h"
+
+namespace {
+
+struct NaArgs {
+  const float* x;
+  int64_t ld_x;
+  const float* gamma;
+  const float* beta;
+  int64_t n;
+  int32_t H;
+  float eps;
+  float p;                 // dropout probability (0 = no dropout)
+  uint32_t flags;          // AGNN_NA_*
+  const int64_t* rng;      // device [2]: seed, step
+  uint32_t call_id;
+};
+
+__device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+
+// Philox-4x32-10 (Salmon et al. 2011): 4 x 32 random bits for counter (c0..c3), key (k0,k1)
+__device__ __forceinline__ uint4 philox(uint4 c, uint2 k) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t h0 = mulhi32(0xD2511F53u, c.x), l0 = 0xD2511F53u * c.x;
+    const uint32_t h1 = mulhi32(0xCD9E8D57u, c.z), l1 = 0xCD9E8D57u * c.z;
+    c = make_uint4(h1 ^ c.y ^ k.x, l1, h0 ^ c.w ^ k.y, l0);
+    k.x += 0x9E3779B9u;
+    k.y += 0xBB67AE85u;
+  }
+  return c;
+}
+
+__device__ __forceinline__ float4 keep_mask(const NaArgs& a, int64_t row, int chunk_lane, float scale) {
+  const uint64_t seed = static_cast<uint64_t>(a.rng[0]), step = static_cast<uint64_t>(a.rng[1]);
+  const uint64_t idx = static_cast<uint64_t>(row) * 256u + static_cast<uint32_t>(chunk_lane);     // one counter per float4
+  const uint4 r = philox(make_uint4(static_cast<uint32_t>(idx), static_cast<uint32_t>(idx >> 32), a.call_id, static_cast<uint32_t>(step)),
+                         make_uint2(static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32) ^ static_cast<uint32_t>(step >> 32)));
+  const uint32_t thr = static_cast<uint32_t>(static_cast<double>(a.p) * 4294967296.0);            // drop when r < thr
+  return make_float4(r.x >= thr ? scale : 0.f, r.y >= thr ? scale : 0.f, r.z >= thr ? scale : 0.f, r.w >= thr ? scale : 0.f);
+}
+
+__device__ __forceinline__ float wsum(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void k_na_fwd(NaArgs a, float* __restrict__ y, int64_t ld_y, float* __restrict__ mean_out,
+                                                float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (row >= a.n) return;
+  const bool pre = a.flags & AGNN_NA_PRE_RELU, post = a.flags & AGNN_NA_POST_RELU, drop = a.p > 0.f;
+  bool on[CH];
+  float4 v[CH];
+  const float4* xp = reinterpret_cast<const float4*>(a.x + row * a.ld_x);
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    on[c] = (c * 256 + lane * 4) < a.H;
+    v[c] = on[c] ? xp[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pre) { v[c].x = fmaxf(v[c].x, 0.f); v[c].y = fmaxf(v[c].y, 0.f); v[c].z = fmaxf(v[c].z, 0.f); v[c].w = fmaxf(v[c].w, 0.f); }
+    s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+  }
+  const float invH = 1.f / static_cast<float>(a.H);
+  const float mean = wsum(s) * invH;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    if (!on[c]) continue;
+    const float dx = v[c].x - mean, dy = v[c].y - mean, dz = v[c].z - mean, dw = v[c].w - mean;
+    q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+  }
+  const float rstd = 1.f / sqrtf(wsum(q) * invH + a.eps);
+  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+  const float scale = drop ? 1.f / (1.f - a.p) : 1.f;
+  float4* yp = reinterpret_cast<float4*>(y + row * ld_y);
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    if (!on[c]) continue;
+    const float4 g = reinterpret_cast<const float4*>(a.gamma)[c * 64 + lane], b = reinterpret_cast<const float4*>(a.beta)[c * 64 + lane];
+    float4 o = make_float4((v[c].x - mean) * rstd * g.x + b.x, (v[c].y - mean) * rstd * g.y + b.y,
+                           (v[c].z - mean) * rstd * g.z + b.z, (v[c].w - mean) * rstd * g.w + b.w);
+    if (post) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    if (drop) {
+      const float4 m = keep_mask(a, row, c * 64 + lane, scale);
+      o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
+    }
+    yp[c * 64 + lane] = o;
+  }
+}
+
+// grid-stride over rows; per-wave partial dgamma / dbeta rows -> part[wave_global][2][H]
+template <int CH>
+__global__ __launch_bounds__(256) void k_na_bwd(NaArgs a, const float* __restrict__ dy, int64_t ld_dy, const float* __restrict__ mean_in,
+                                                const float* __restrict__ rstd_in, float* __restrict__ dx, int64_t ld_dx,
+                                                float* __restrict__ part) {
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n_waves = gridDim.x * 4;
+  const bool pre = a.flags & AGNN_NA_PRE_RELU, post = a.flags & AGNN_NA_POST_RELU, drop = a.p > 0.f;
+  const float scale = drop ? 1.f / (1.f - a.p) : 1.f;
+  const float invH = 1.f / static_cast<float>(a.H);
+  bool on[CH];
+  float4 gm[CH], bt[CH], dg[CH], db[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    on[c] = (c * 256 + lane * 4) < a.H;
+    gm[c] = on[c] ? reinterpret_cast<const float4*>(a.gamma)[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    bt[c] = on[c] ? reinterpret_cast<const float4*>(a.beta)[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    dg[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    db[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int64_t row = wave_g; row < a.n; row += n_waves) {
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    const float4* xp = reinterpret_cast<const float4*>(a.x + row * a.ld_x);
+    const float4* gp = reinterpret_cast<const float4*>(dy + row * ld_dy);
+    float4 xr[CH], xh[CH], gx[CH];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      xr[c] = on[c] ? xp[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 g = on[c] ? gp[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 v = xr[c];
+      if (pre) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      xh[c] = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
+      if (!on[c]) xh[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (drop) {
+        const float4 m = keep_mask(a, row, c * 64 + lane, scale);
+        g.x *= m.x; g.y *= m.y; g.z *= m.z; g.w *= m.w;
+      }
+      if (post) {
+        if (xh[c].x * gm[c].x + bt[c].x <= 0.f) g.x = 0.f;
+        if (xh[c].y * gm[c].y + bt[c].y <= 0.f) g.y = 0.f;
+        if (xh[c].z * gm[c].z + bt[c].z <= 0.f) g.z = 0.f;
+        if (xh[c].w * gm[c].w + bt[c].w <= 0.f) g.w = 0.f;
+      }
+      dg[c].x += g.x * xh[c].x; dg[c].y += g.y * xh[c].y; dg[c].z += g.z * xh[c].z; dg[c].w += g.w * xh[c].w;
+      db[c].x += g.x; db[c].y += g.y; db[c].z += g.z; db[c].w += g.w;
+      gx[c] = make_float4(g.x * gm[c].x, g.y * gm[c].y, g.z * gm[c].z, g.w * gm[c].w);           // d xhat
+      s1 += (gx[c].x + gx[c].y) + (gx[c].z + gx[c].w);
+      s2 += (gx[c].x * xh[c].x + gx[c].y * xh[c].y) + (gx[c].z * xh[c].z + gx[c].w * xh[c].w);
+    }
+    const float m1 = wsum(s1) * invH, m2 = wsum(s2) * invH;
+    float4* op = reinterpret_cast<float4*>(dx + row * ld_dx);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (!on[c]) continue;
+      float4 o = make_float4(rstd * (gx[c].x - m1 - xh[c].x * m2), rstd * (gx[c].y - m1 - xh[c].y * m2),
+                             rstd * (gx[c].z - m1 - xh[c].z * m2), rstd * (gx[c].w - m1 - xh[c].w * m2));
+      if (pre) {
+        if (xr[c].x <= 0.f) o.x = 0.f;
+        if (xr[c].y <= 0.f) o.y = 0.f;
+        if (xr[c].z <= 0.f) o.z = 0.f;
+        if (xr[c].w <= 0.f) o.w = 0.f;
+      }
+      op[c * 64 + lane] = o;
+    }
+  }
+  float4* pg = reinterpret_cast<float4*>(part + static_cast<int64_t>(wave_g) * 2 * a.H);
+  float4* pb = reinterpret_cast<float4*>(part + static_cast<int64_t>(wave_g) * 2 * a.H + a.H);
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    if (!on[c]) continue;
+    pg[c * 64 + lane] = dg[c];
+    pb[c * 64 + lane] = db[c];
+  }
+}
+
+// out[j] = sum_w part[w][j]  for j < 2H  (columns: dgamma | dbeta).  Block = 32 columns x 8 row groups.
+__global__ __launch_bounds__(256) void k_na_colsum(const float* __restrict__ part, int n_waves, int width, float* __restrict__ dgamma,
+                                                   float* __restrict__ dbeta, int H) {
+  __shared__ float sm[8][32];
+  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + col;
+  float s = 0.f;
+  if (j < width)
+    for (int w = grp; w < n_waves; w += 8) s += part[static_cast<int64_t>(w) * width + j];
+  sm[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && j < width) {
+    float t = sm[0][col];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += sm[g][col];
+    if (j < H) dgamma[j] = t; else dbeta[j - H] = t;
+  }
+}
+
+constexpr int kBwdBlocks = 256;     // 1024 waves: partial slab = 1024 * 2H floats
+
+int na_check(const char* who, const void* x, int64_t ld_x, const void* gamma, const void* beta, int64_t n, int32_t H, float p,
+             const void* rng) {
+  using namespace agnn;
+  if (n < 0 || H <= 0 || (H & 3) || H > 1024) return fail(AGNN_EINVAL, "%s: H=%d must be a multiple of 4 in [4,1024], n=%lld", who, H, (long long)n);
+  if (p < 0.f || p >= 1.f) return fail(AGNN_EINVAL, "%s: dropout p=%f", who, p);
+  if (n == 0) return 1;
+  if (!x || !gamma || !beta) return fail(AGNN_EINVAL, "%s: null argument", who);
+  if (p > 0.f && !rng) return fail(AGNN_EINVAL, "%s: dropout needs the device rng state", who);
+  if (!aligned16(x) || !aligned16(gamma) || !aligned16(beta) || (ld_x & 3) || ld_x < H) return fail(AGNN_EALIGN, "%s: misaligned", who);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t agnn_norm_act_workspace_bytes(int32_t H) { return static_cast<size_t>(kBwdBlocks) * 4 * 2 * static_cast<size_t>(H > 0 ? H : 0) * sizeof(float); }
+
+extern "C" int agnn_norm_act_fwd_f32(const float* x, int64_t ld_x, const float* gamma, const float* beta, int64_t n, int32_t H,
+                                     float eps, float p, uint32_t flags, const int64_t* rng_state, uint32_t call_id, float* y,
+                                     int64_t ld_y, float* mean, float* rstd, agnn_stream_t stream_) {
+  using namespace agnn;
+  if (int rc = na_check("norm_act_fwd", x, ld_x, gamma, beta, n, H, p, rng_state)) return rc > 0 ? AGNN_OK : rc;
+  if (!y || !mean || !rstd || !aligned16(y) || (ld_y & 3) || ld_y < H) return fail(AGNN_EALIGN, "norm_act_fwd: output misaligned");
+  NaArgs a{x, ld_x, gamma, beta, n, H, eps, p, flags, rng_state, call_id};
+  const dim3 grid(static_cast<unsigned>((n + 3) / 4)), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  if (H <= 256) hipLaunchKernelGGL(k_na_fwd<1>, grid, block, 0, s, a, y, ld_y, mean, rstd);
+  else if (H <= 512) hipLaunchKernelGGL(k_na_fwd<2>, grid, block, 0, s, a, y, ld_y, mean, rstd);
+  else hipLaunchKernelGGL(k_na_fwd<4>, grid, block, 0, s, a, y, ld_y, mean, rstd);
+  return check_launch("norm_act_fwd");
+}
+
+extern "C" int agnn_norm_act_bwd_f32(const float* x, int64_t ld_x, const float* gamma, const float* beta, int64_t n, int32_t H,
+                                     float eps, float p, uint32_t flags, const int64_t* rng_state, uint32_t call_id,
+                                     const float* dy, int64_t ld_dy, const float* mean, const float* rstd, float* dx, int64_t ld_dx,
+                                     float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, agnn_stream_t stream_) {
+  using namespace agnn;
+  if (int rc = na_check("norm_act_bwd", x, ld_x, gamma, beta, n, H, p, rng_state)) return rc > 0 ? AGNN_OK : rc;
+  if (!dy || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace) return fail(AGNN_EINVAL, "norm_act_bwd: null argument");
+  if (!aligned16(dy) || !aligned16(dx) || !aligned16(workspace) || (ld_dy & 3) || (ld_dx & 3)) return fail(AGNN_EALIGN, "norm_act_bwd: misaligned");
+  if (workspace_bytes < agnn_norm_act_workspace_bytes(H)) return fail(AGNN_ENOMEM, "norm_act_bwd: workspace too small");
+  NaArgs a{x, ld_x, gamma, beta, n, H, eps, p, flags, rng_state, call_id};
+  float* part = static_cast<float*>(workspace);
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  const dim3 grid(kBwdBlocks), block(256);
+  if (H <= 256) hipLaunchKernelGGL(k_na_bwd<1>, grid, block, 0, s, a, dy, ld_dy, mean, rstd, dx, ld_dx, part);
+  else if (H <= 512) hipLaunchKernelGGL(k_na_bwd<2>, grid, block, 0, s, a, dy, ld_dy, mean, rstd, dx, ld_dx, part);
+  else hipLaunchKernelGGL(k_na_bwd<4>, grid, block, 0, s, a, dy, ld_dy, mean, rstd, dx, ld_dx, part);
+  if (int rc = check_launch("norm_act_bwd")) return rc;
+  const int width = 2 * H;
+  hipLaunchKernelGGL(k_na_colsum, dim3((width + 31) / 32), dim3(256), 0, s, part, kBwdBlocks * 4, width, dgamma, dbeta, H);
+  return check_launch("norm_act_colsum");
+}

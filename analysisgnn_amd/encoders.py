@@ -31,6 +31,7 @@ import torch.nn.functional as F
 
 from . import _lib, ops
 from .gru import gru_forward
+from .fused import FusedSequential, norm_act
 from .linear import Linear, linear
 from .core_layers import JumpingKnowledge
 from .graph import HeteroIndex, hetero_index
@@ -169,7 +170,7 @@ class HeteroSAGEStack(nn.Module):
             x_dict = {k: v for k, v in x_dict.items()}
             x_dict = conv(x_dict, edge_index_dict, index, keep, plan.e_keep[i])
             if i < self.num_layers - 1:
-                x_dict = {k: F.dropout(F.relu(self.layer_norms[i](v)), self.dropout, self.training)
+                x_dict = {k: norm_act(v, self.layer_norms[i], post_relu=True, p=self.dropout, training=self.training)
                           for k, v in x_dict.items()}
             if collect is not None:
                 collect.append(x_dict["note"])
@@ -216,7 +217,7 @@ class _HybridMixin:
         self.rnn = nn.GRU(input_size=input_channels, hidden_size=hidden_channels // 2, num_layers=2,
                           batch_first=True, bidirectional=True, dropout=dropout)
         self.rnn_norm = nn.LayerNorm(hidden_channels)
-        self.rnn_mlp = nn.Sequential(Linear(hidden_channels, hidden_channels), nn.ReLU(),
+        self.rnn_mlp = FusedSequential(Linear(hidden_channels, hidden_channels), nn.ReLU(),
                                      nn.LayerNorm(hidden_channels), nn.Dropout(dropout),
                                      Linear(hidden_channels, hidden_channels))
         self.cat_proj = Linear(hidden_channels * 2, hidden_channels)
@@ -226,11 +227,11 @@ class _HybridMixin:
         if len(set(lens)) == 1:                     # equal windows (the usual batch): a view, no padding
             y = x.view(len(lens), lens[0], x.shape[1])
             y = gru_forward(self.rnn, y, self.training)
-            y = self.rnn_mlp(self.rnn_norm(y))
+            y = self.rnn_mlp(norm_act(y, self.rnn_norm))
             return y.reshape(-1, y.shape[-1])
         seqs = nn.utils.rnn.pad_sequence(x.split(lens), batch_first=True, padding_value=0.0)
         y = gru_forward(self.rnn, seqs, self.training)
-        y = self.rnn_mlp(self.rnn_norm(y))
+        y = self.rnn_mlp(norm_act(y, self.rnn_norm))
         return torch.cat(nn.utils.rnn.unpad_sequence(y, batch_first=True, lengths=lengths.cpu()), dim=0)
 
     # The sequence branch only needs the encoder INPUT, so it runs on a second HIP stream beside the
@@ -306,7 +307,7 @@ class MetricalGNN(nn.Module):
         self.use_jk = bool(use_jk)
         if self.use_jk:
             self.jk = JumpingKnowledge(hidden_channels, num_layers)
-        self.mlp = nn.Sequential(Linear(hidden_channels, hidden_channels), nn.ReLU(),
+        self.mlp = FusedSequential(Linear(hidden_channels, hidden_channels), nn.ReLU(),
                                  nn.LayerNorm(hidden_channels), nn.Dropout(dropout),
                                  Linear(hidden_channels, output_channels))
 

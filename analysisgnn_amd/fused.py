@@ -1,0 +1,115 @@
+"""Fused [ReLU ->] LayerNorm [-> ReLU] [-> dropout] (C-ABI `agnn_norm_act_*`) and an `nn.Sequential` drop-in that
+recognises those chains.  Parameters stay in the ordinary `nn.LayerNorm` / `nn.Linear` modules (`state_dict`
+unchanged); only the schedule differs.  Dropout uses the library's own counter-based generator: masks are a pure
+function of (seed, training step, call site, element), so backward regenerates them instead of storing them."""
+from __future__ import annotations
+
+import itertools
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+PRE_RELU, POST_RELU = 1, 2
+ENABLED = True
+_RNG: Dict[str, torch.Tensor] = {}
+_CALL_IDS = itertools.count(1)
+
+
+def rng_state(device) -> torch.Tensor:
+    """Device int64[2] = (seed, step).  `advance_rng` bumps the step (one tiny in-stream launch, graph-safe)."""
+    key = str(device)
+    if key not in _RNG:
+        _RNG[key] = torch.tensor([int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+    return _RNG[key]
+
+
+def advance_rng(device) -> None:
+    rng_state(device)[1] += 1
+
+
+class _NormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, p, flags, call_id):
+        dev = _lib.require_gpu(x, gamma, beta)
+        lib = _lib.load()
+        x = x if (x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else x.contiguous()
+        n, H = x.shape
+        y = torch.empty((n, H), dtype=torch.float32, device=dev)
+        mean = torch.empty((max(n, 1),), dtype=torch.float32, device=dev)
+        rstd = torch.empty((max(n, 1),), dtype=torch.float32, device=dev)
+        rng = rng_state(dev) if p > 0 else None
+        gamma, beta = gamma.contiguous(), beta.contiguous()
+        _lib.check(lib.agnn_norm_act_fwd_f32(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), n, H, float(eps), float(p),
+                                             int(flags), _lib.ptr(rng), int(call_id), y.data_ptr(), y.stride(0), mean.data_ptr(),
+                                             rstd.data_ptr(), _lib.stream_ptr(dev)), "agnn_norm_act_fwd_f32")
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.cfg = (float(eps), float(p), int(flags), int(call_id))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        eps, p, flags, call_id = ctx.cfg
+        dev = dy.device
+        lib = _lib.load()
+        dy = dy if (dy.stride(1) == 1 and dy.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0) else dy.contiguous()
+        n, H = x.shape
+        dx = torch.empty_like(x)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(beta)
+        nws = int(lib.agnn_norm_act_workspace_bytes(H))
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        rng = rng_state(dev) if p > 0 else None
+        _lib.check(lib.agnn_norm_act_bwd_f32(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), n, H, eps, p, flags,
+                                             _lib.ptr(rng), call_id, dy.data_ptr(), dy.stride(0), mean.data_ptr(), rstd.data_ptr(),
+                                             dx.data_ptr(), dx.stride(0), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), nws,
+                                             _lib.stream_ptr(dev)), "agnn_norm_act_bwd_f32")
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+def norm_act(x: torch.Tensor, ln: nn.LayerNorm, pre_relu: bool = False, post_relu: bool = False, p: float = 0.0,
+             training: bool = False) -> torch.Tensor:
+    """dropout_p( relu?( LayerNorm( relu?(x) ) ) ) on the last dimension of x (2-D or 3-D, fp32, H % 4 == 0)."""
+    H = x.shape[-1]
+    usable = (ENABLED and x.is_cuda and x.dtype == torch.float32 and H % 4 == 0 and H <= 1024 and ln.elementwise_affine
+              and tuple(ln.normalized_shape) == (H,))
+    if not usable:
+        y = F.relu(x) if pre_relu else x
+        y = ln(y)
+        y = F.relu(y) if post_relu else y
+        return F.dropout(y, p, training)
+    x2 = x.reshape(-1, H)
+    flags = (PRE_RELU if pre_relu else 0) | (POST_RELU if post_relu else 0)
+    y = _NormAct.apply(x2, ln.weight, ln.bias, ln.eps, p if training else 0.0, flags, next(_CALL_IDS) & 0xFFFFFFFF)
+    return y.view(x.shape)
+
+
+class FusedSequential(nn.Sequential):
+    """`nn.Sequential` whose forward runs `ReLU -> LayerNorm [-> Dropout]`, `LayerNorm [-> ReLU] [-> Dropout]` chains
+    through `norm_act`; every other module runs as usual.  Module indices (and so `state_dict` keys) are untouched."""
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            nn2 = mods[i + 2] if i + 2 < len(mods) else None
+            if isinstance(m, nn.ReLU) and isinstance(nxt, nn.LayerNorm):
+                p, used = (nn2.p, 3) if isinstance(nn2, nn.Dropout) else (0.0, 2)
+                x = norm_act(x, nxt, pre_relu=True, p=p, training=self.training)
+                i += used
+            elif isinstance(m, nn.LayerNorm):
+                post = isinstance(nxt, nn.ReLU)
+                d = mods[i + 1 + int(post)] if i + 1 + int(post) < len(mods) else None
+                p = d.p if isinstance(d, nn.Dropout) else 0.0
+                x = norm_act(x, m, post_relu=post, p=p, training=self.training)
+                i += 1 + int(post) + int(isinstance(d, nn.Dropout))
+            else:
+                x = m(x)
+                i += 1
+        return x

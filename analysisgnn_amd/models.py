@@ -12,6 +12,7 @@ import torch.nn as nn
 
 from . import _lib, ops
 from .encoders import HybridGNN, MetricalGNN
+from .fused import FusedSequential, advance_rng
 from .heads import fused_head_logits
 from .linear import Linear
 from .graph import SegSpec, build_csr
@@ -40,7 +41,7 @@ def onset_pool(x: torch.Tensor, onset_edges: torch.Tensor, batch_size: int, inde
 
 
 def _input_mlp(i, h, dropout):
-    return nn.Sequential(Linear(i, h), nn.ReLU(), nn.LayerNorm(h), nn.Dropout(dropout), Linear(h, h))
+    return FusedSequential(Linear(i, h), nn.ReLU(), nn.LayerNorm(h), nn.Dropout(dropout), Linear(h, h))
 
 
 class TorchAnalysisGNN(nn.Module):
@@ -70,7 +71,7 @@ class TorchAnalysisGNN(nn.Module):
         else:
             raise ValueError(encoder_type)
         h, o = hidden_channels, out_channels
-        self.project_enc = nn.Sequential(
+        self.project_enc = FusedSequential(
             nn.LayerNorm(2 * h), Linear(2 * h, h), nn.ReLU(), nn.LayerNorm(h), nn.Dropout(dropout),
             Linear(h, o), nn.ReLU(), nn.LayerNorm(o), nn.Dropout(dropout), Linear(o, o))
         self.clf_dict = nn.ModuleDict({
@@ -79,6 +80,8 @@ class TorchAnalysisGNN(nn.Module):
 
     def encode(self, pitch_spelling, key_signature, x_dict, edge_index_dict, batch_dict, batch_size,
                neighbor_mask_node, neighbor_mask_edge):
+        if self.training:
+            advance_rng(x_dict["note"].device)          # fresh dropout masks for this step (device-side counter)
         z_dict = dict(x_dict)
         z_dict["note"] = torch.cat([z_dict["note"], self.pitch_embedding(pitch_spelling),
                                     self.key_embedding(key_signature)], dim=-1)

@@ -16,6 +16,7 @@
  *                         `HeteroConv` (ref: models/cadence.py:147-159,174)
  *   agnn_gru_fwd/bwd_f32  `torch.nn.GRU` of the hybrid sequence branch (ref: models/cadence.py:249-285)
  *   agnn_gated_*          `ResGatedGraphConv` edge gate + scatter (ref: core/gnn.py:246-257)
+ *   agnn_norm_act_*       LayerNorm / ReLU / Dropout chains between the projections (ref: models/analysis.py:429-443)
  *   agnn_wgrad_f32        weight/bias gradients of the dense projections (fp32 MFMA, split over N)
  *   agnn_multitask_ce_f32 the 21 per-task CrossEntropyLoss terms (ref: models/analysis.py:881-888)
  *   agnn_hgt_attn_*       PyG `HGTConv` message/softmax/aggregate, reached through graphmuse
@@ -210,6 +211,25 @@ int agnn_gated_bwd_dst_f32(const agnn_gated_t* g /* (host) */, const float* ds, 
                            float* dc, agnn_stream_t stream);
 int agnn_gated_bwd_src_f32(const agnn_gated_t* g /* (host) */, const float* ds, int64_t ld_ds, float* db,
                            float* dh, agnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused [ReLU ->] LayerNorm [-> ReLU] [-> dropout] over the rows of x [n, H] (the element-wise chains between the
+ * projections, ref: models/analysis.py:429-443, :474-485; models/cadence.py:252-259).  Saves mean / rstd [n];
+ * backward recomputes the ReLU masks from x and the dropout mask from the counter-based generator:
+ * Philox-4x32-10(seed = rng_state[0], counter = (element, call_id, step = rng_state[1])), rng_state a DEVICE
+ * int64[2] so a captured graph draws new masks when the caller bumps the step between replays.
+ * ------------------------------------------------------------------------------------------ */
+#define AGNN_NA_PRE_RELU  1u
+#define AGNN_NA_POST_RELU 2u
+size_t agnn_norm_act_workspace_bytes(int32_t H);
+int agnn_norm_act_fwd_f32(const float* x, int64_t ld_x, const float* gamma, const float* beta, int64_t n, int32_t H,
+                          float eps, float p, uint32_t flags, const int64_t* rng_state, uint32_t call_id, float* y,
+                          int64_t ld_y, float* mean, float* rstd, agnn_stream_t stream);
+int agnn_norm_act_bwd_f32(const float* x, int64_t ld_x, const float* gamma, const float* beta, int64_t n, int32_t H,
+                          float eps, float p, uint32_t flags, const int64_t* rng_state, uint32_t call_id,
+                          const float* dy, int64_t ld_dy, const float* mean, const float* rstd, float* dx,
+                          int64_t ld_dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                          agnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Weight-gradient GEMM of a projection layer y = x W^T + b over N rows (N large, out/in small):
