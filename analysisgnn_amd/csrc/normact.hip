@@ -28,6 +28,7 @@ struct NaArgs {
   uint32_t flags;          // AGNN_NA_*
   const int64_t* rng;      // device [2]: seed, step
   uint32_t call_id;
+  int32_t n_groups;        // gamma / beta are [n_groups, H]; row r uses group r % n_groups (1 = plain LayerNorm)
 };
 
 __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
@@ -90,10 +91,11 @@ __global__ __launch_bounds__(256) void k_na_fwd(NaArgs a, float* __restrict__ y,
   if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
   const float scale = drop ? 1.f / (1.f - a.p) : 1.f;
   float4* yp = reinterpret_cast<float4*>(y + row * ld_y);
+  const int64_t goff = (a.n_groups > 1 ? (row % a.n_groups) : 0) * static_cast<int64_t>(a.H);
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     if (!on[c]) continue;
-    const float4 g = reinterpret_cast<const float4*>(a.gamma)[c * 64 + lane], b = reinterpret_cast<const float4*>(a.beta)[c * 64 + lane];
+    const float4 g = reinterpret_cast<const float4*>(a.gamma + goff)[c * 64 + lane], b = reinterpret_cast<const float4*>(a.beta + goff)[c * 64 + lane];
     float4 o = make_float4((v[c].x - mean) * rstd * g.x + b.x, (v[c].y - mean) * rstd * g.y + b.y,
                            (v[c].z - mean) * rstd * g.z + b.z, (v[c].w - mean) * rstd * g.w + b.w);
     if (post) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
@@ -118,11 +120,13 @@ __global__ __launch_bounds__(256) void k_na_bwd(NaArgs a, const float* __restric
   const float invH = 1.f / static_cast<float>(a.H);
   bool on[CH];
   float4 gm[CH], bt[CH], dg[CH], db[CH];
+  // the launch makes n_waves a multiple of n_groups, so every row of this wave belongs to group wave_g % n_groups
+  const int64_t goff = (a.n_groups > 1 ? (wave_g % a.n_groups) : 0) * static_cast<int64_t>(a.H);
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     on[c] = (c * 256 + lane * 4) < a.H;
-    gm[c] = on[c] ? reinterpret_cast<const float4*>(a.gamma)[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-    bt[c] = on[c] ? reinterpret_cast<const float4*>(a.beta)[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    gm[c] = on[c] ? reinterpret_cast<const float4*>(a.gamma + goff)[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    bt[c] = on[c] ? reinterpret_cast<const float4*>(a.beta + goff)[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
     dg[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     db[c] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -182,26 +186,27 @@ __global__ __launch_bounds__(256) void k_na_bwd(NaArgs a, const float* __restric
   }
 }
 
-// out[j] = sum_w part[w][j]  for j < 2H  (columns: dgamma | dbeta).  Block = 32 columns x 8 row groups.
-__global__ __launch_bounds__(256) void k_na_colsum(const float* __restrict__ part, int n_waves, int width, float* __restrict__ dgamma,
+// dgamma[g][j] | dbeta[g][j] = sum over waves w with w % G == g of part[w][j | H + j].  Block = 32 columns x 8 partial sums.
+__global__ __launch_bounds__(256) void k_na_colsum(const float* __restrict__ part, int n_waves, int width, int G, float* __restrict__ dgamma,
                                                    float* __restrict__ dbeta, int H) {
   __shared__ float sm[8][32];
   const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int j = blockIdx.x * 32 + col;
+  const int g = blockIdx.y;
   float s = 0.f;
   if (j < width)
-    for (int w = grp; w < n_waves; w += 8) s += part[static_cast<int64_t>(w) * width + j];
+    for (int w = g + grp * G; w < n_waves; w += 8 * G) s += part[static_cast<int64_t>(w) * width + j];
   sm[grp][col] = s;
   __syncthreads();
   if (grp == 0 && j < width) {
     float t = sm[0][col];
 #pragma unroll
-    for (int g = 1; g < 8; ++g) t += sm[g][col];
-    if (j < H) dgamma[j] = t; else dbeta[j - H] = t;
+    for (int k = 1; k < 8; ++k) t += sm[k][col];
+    if (j < H) dgamma[static_cast<int64_t>(g) * H + j] = t; else dbeta[static_cast<int64_t>(g) * H + j - H] = t;
   }
 }
 
-constexpr int kBwdBlocks = 256;     // 1024 waves: partial slab = 1024 * 2H floats
+constexpr int kBwdBlocks = 256;     // up to 1024 waves: partial slab = 1024 * 2H floats
 
 int na_check(const char* who, const void* x, int64_t ld_x, const void* gamma, const void* beta, int64_t n, int32_t H, float p,
              const void* rng) {
@@ -217,15 +222,16 @@ int na_check(const char* who, const void* x, int64_t ld_x, const void* gamma, co
 
 }  // namespace
 
-extern "C" size_t agnn_norm_act_workspace_bytes(int32_t H) { return static_cast<size_t>(kBwdBlocks) * 4 * 2 * static_cast<size_t>(H > 0 ? H : 0) * sizeof(float); }
+extern "C" size_t agnn_norm_act_workspace_bytes(int32_t H) { return (static_cast<size_t>(kBwdBlocks) * 4 + 1024) * 2 * static_cast<size_t>(H > 0 ? H : 0) * sizeof(float); }
 
-extern "C" int agnn_norm_act_fwd_f32(const float* x, int64_t ld_x, const float* gamma, const float* beta, int64_t n, int32_t H,
-                                     float eps, float p, uint32_t flags, const int64_t* rng_state, uint32_t call_id, float* y,
-                                     int64_t ld_y, float* mean, float* rstd, agnn_stream_t stream_) {
+extern "C" int agnn_norm_act_fwd_f32(const float* x, int64_t ld_x, const float* gamma, const float* beta, int32_t n_groups, int64_t n,
+                                     int32_t H, float eps, float p, uint32_t flags, const int64_t* rng_state, uint32_t call_id,
+                                     float* y, int64_t ld_y, float* mean, float* rstd, agnn_stream_t stream_) {
   using namespace agnn;
   if (int rc = na_check("norm_act_fwd", x, ld_x, gamma, beta, n, H, p, rng_state)) return rc > 0 ? AGNN_OK : rc;
   if (!y || !mean || !rstd || !aligned16(y) || (ld_y & 3) || ld_y < H) return fail(AGNN_EALIGN, "norm_act_fwd: output misaligned");
-  NaArgs a{x, ld_x, gamma, beta, n, H, eps, p, flags, rng_state, call_id};
+  if (n_groups < 1 || n_groups > 256) return fail(AGNN_EINVAL, "norm_act_fwd: n_groups=%d", n_groups);
+  NaArgs a{x, ld_x, gamma, beta, n, H, eps, p, flags, rng_state, call_id, n_groups};
   const dim3 grid(static_cast<unsigned>((n + 3) / 4)), block(256);
   hipStream_t s = static_cast<hipStream_t>(stream_);
   if (H <= 256) hipLaunchKernelGGL(k_na_fwd<1>, grid, block, 0, s, a, y, ld_y, mean, rstd);
@@ -234,8 +240,8 @@ extern "C" int agnn_norm_act_fwd_f32(const float* x, int64_t ld_x, const float* 
   return check_launch("norm_act_fwd");
 }
 
-extern "C" int agnn_norm_act_bwd_f32(const float* x, int64_t ld_x, const float* gamma, const float* beta, int64_t n, int32_t H,
-                                     float eps, float p, uint32_t flags, const int64_t* rng_state, uint32_t call_id,
+extern "C" int agnn_norm_act_bwd_f32(const float* x, int64_t ld_x, const float* gamma, const float* beta, int32_t n_groups, int64_t n,
+                                     int32_t H, float eps, float p, uint32_t flags, const int64_t* rng_state, uint32_t call_id,
                                      const float* dy, int64_t ld_dy, const float* mean, const float* rstd, float* dx, int64_t ld_dx,
                                      float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, agnn_stream_t stream_) {
   using namespace agnn;
@@ -243,15 +249,21 @@ extern "C" int agnn_norm_act_bwd_f32(const float* x, int64_t ld_x, const float* 
   if (!dy || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace) return fail(AGNN_EINVAL, "norm_act_bwd: null argument");
   if (!aligned16(dy) || !aligned16(dx) || !aligned16(workspace) || (ld_dy & 3) || (ld_dx & 3)) return fail(AGNN_EALIGN, "norm_act_bwd: misaligned");
   if (workspace_bytes < agnn_norm_act_workspace_bytes(H)) return fail(AGNN_ENOMEM, "norm_act_bwd: workspace too small");
-  NaArgs a{x, ld_x, gamma, beta, n, H, eps, p, flags, rng_state, call_id};
+  if (n_groups < 1 || n_groups > 256) return fail(AGNN_EINVAL, "norm_act_bwd: n_groups=%d", n_groups);
+  NaArgs a{x, ld_x, gamma, beta, n, H, eps, p, flags, rng_state, call_id, n_groups};
   float* part = static_cast<float*>(workspace);
   hipStream_t s = static_cast<hipStream_t>(stream_);
-  const dim3 grid(kBwdBlocks), block(256);
+  // number of waves: a multiple of 4 (waves per block) and of n_groups, at most kBwdBlocks * 4
+  int lcm = n_groups;
+  while (lcm % 4) lcm += n_groups;
+  int n_waves = (kBwdBlocks * 4 / lcm) * lcm;
+  if (n_waves < lcm) n_waves = lcm;
+  const dim3 grid(n_waves / 4), block(256);
   if (H <= 256) hipLaunchKernelGGL(k_na_bwd<1>, grid, block, 0, s, a, dy, ld_dy, mean, rstd, dx, ld_dx, part);
   else if (H <= 512) hipLaunchKernelGGL(k_na_bwd<2>, grid, block, 0, s, a, dy, ld_dy, mean, rstd, dx, ld_dx, part);
   else hipLaunchKernelGGL(k_na_bwd<4>, grid, block, 0, s, a, dy, ld_dy, mean, rstd, dx, ld_dx, part);
   if (int rc = check_launch("norm_act_bwd")) return rc;
   const int width = 2 * H;
-  hipLaunchKernelGGL(k_na_colsum, dim3((width + 31) / 32), dim3(256), 0, s, part, kBwdBlocks * 4, width, dgamma, dbeta, H);
+  hipLaunchKernelGGL(k_na_colsum, dim3((width + 31) / 32, n_groups), dim3(256), 0, s, part, n_waves, width, n_groups, dgamma, dbeta, H);
   return check_launch("norm_act_colsum");
 }

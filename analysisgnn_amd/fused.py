@@ -34,6 +34,7 @@ def advance_rng(device) -> None:
 class _NormAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, p, flags, call_id):
+        """gamma / beta: [H] or [G, H] (row r of x uses group r % G)."""
         dev = _lib.require_gpu(x, gamma, beta)
         lib = _lib.load()
         x = x if (x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else x.contiguous()
@@ -43,7 +44,8 @@ class _NormAct(torch.autograd.Function):
         rstd = torch.empty((max(n, 1),), dtype=torch.float32, device=dev)
         rng = rng_state(dev) if p > 0 else None
         gamma, beta = gamma.contiguous(), beta.contiguous()
-        _lib.check(lib.agnn_norm_act_fwd_f32(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), n, H, float(eps), float(p),
+        G = gamma.shape[0] if gamma.dim() == 2 else 1
+        _lib.check(lib.agnn_norm_act_fwd_f32(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), G, n, H, float(eps), float(p),
                                              int(flags), _lib.ptr(rng), int(call_id), y.data_ptr(), y.stride(0), mean.data_ptr(),
                                              rstd.data_ptr(), _lib.stream_ptr(dev)), "agnn_norm_act_fwd_f32")
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
@@ -64,7 +66,8 @@ class _NormAct(torch.autograd.Function):
         nws = int(lib.agnn_norm_act_workspace_bytes(H))
         ws = torch.empty(nws, dtype=torch.uint8, device=dev)
         rng = rng_state(dev) if p > 0 else None
-        _lib.check(lib.agnn_norm_act_bwd_f32(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), n, H, eps, p, flags,
+        G = gamma.shape[0] if gamma.dim() == 2 else 1
+        _lib.check(lib.agnn_norm_act_bwd_f32(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), G, n, H, eps, p, flags,
                                              _lib.ptr(rng), call_id, dy.data_ptr(), dy.stride(0), mean.data_ptr(), rstd.data_ptr(),
                                              dx.data_ptr(), dx.stride(0), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), nws,
                                              _lib.stream_ptr(dev)), "agnn_norm_act_bwd_f32")
@@ -86,6 +89,17 @@ def norm_act(x: torch.Tensor, ln: nn.LayerNorm, pre_relu: bool = False, post_rel
     flags = (PRE_RELU if pre_relu else 0) | (POST_RELU if post_relu else 0)
     y = _NormAct.apply(x2, ln.weight, ln.bias, ln.eps, p if training else 0.0, flags, next(_CALL_IDS) & 0xFFFFFFFF)
     return y.view(x.shape)
+
+
+def grouped_norm_act(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, pre_relu: bool = False) -> torch.Tensor:
+    """x [N, G, H] -> LayerNorm over H with per-group affine gamma/beta [G, H] (optionally ReLU first): the G task heads'
+    `ReLU -> LayerNorm` of one note in one launch (models/analysis.py:488-493)."""
+    N, G, H = x.shape
+    if not (ENABLED and x.is_cuda and x.dtype == torch.float32 and H % 4 == 0 and H <= 1024 and G <= 256):
+        y = F.relu(x) if pre_relu else x
+        return F.layer_norm(y, (H,), None, None, eps) * gamma + beta
+    y = _NormAct.apply(x.reshape(N * G, H), gamma, beta, eps, 0.0, PRE_RELU if pre_relu else 0, next(_CALL_IDS) & 0xFFFFFFFF)
+    return y.view(N, G, H)
 
 
 class FusedSequential(nn.Sequential):

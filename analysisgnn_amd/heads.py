@@ -19,6 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
+from .fused import grouped_norm_act
 from .linear import linear
 
 
@@ -29,10 +30,10 @@ def fused_head_logits(clf_dict: nn.ModuleDict, x: torch.Tensor, tasks: Sequence[
     h2 = mods[0][0].out_features
     W1 = torch.cat([m[0].weight for m in mods], dim=0)                    # [T*h2, o]
     b1 = torch.cat([m[0].bias for m in mods], dim=0)
-    a = F.relu(linear(x, W1, b1))                                         # [N, T*h2]
+    a = linear(x, W1, b1)                                                 # [N, T*h2]
     gamma = torch.stack([m[2].weight for m in mods])                      # [T, h2]
     beta = torch.stack([m[2].bias for m in mods])
-    a = F.layer_norm(a.view(-1, T, h2), (h2,), None, None, mods[0][2].eps) * gamma + beta
+    a = grouped_norm_act(a.view(-1, T, h2), gamma, beta, mods[0][2].eps, pre_relu=True)   # ReLU + per-task LayerNorm, one launch
     W2 = torch.block_diag(*[m[3].weight for m in mods])                   # [sum C, T*h2]
     b2 = torch.cat([m[3].bias for m in mods], dim=0)
     logits = linear(a.reshape(-1, T * h2), W2, b2)

@@ -81,3 +81,23 @@ def test_fused_sequential_matches_sequential_in_eval():
     assert_close(b(x), a(x), 1e-4)
     x3 = torch.randn(4, 25, 64, device=DEV)
     assert_close(b(x3), a(x3), 1e-4)
+
+
+def test_grouped_norm_act_matches_per_task_layernorm():
+    """[N, T, 64] activations of the T task heads: ReLU + LayerNorm with per-task affine in one launch."""
+    from analysisgnn_amd.fused import grouped_norm_act
+    torch.manual_seed(3)
+    N, T, H = 1000, 21, 64
+    x = torch.randn(N, T, H)
+    gamma, beta = torch.rand(T, H) + 0.5, torch.randn(T, H) * 0.2
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.layer_norm(F.relu(xr), (H,), None, None, 1e-5) * gr + br
+    g = torch.randn(N, T, H)
+    (ref * g).sum().backward()
+    xg, gg, bg = (t.to(DEV).requires_grad_(True) for t in (x, gamma, beta))
+    out = grouped_norm_act(xg, gg, bg, 1e-5, pre_relu=True)
+    assert_close(out, ref, 1e-4, "y")
+    (out * g.to(DEV)).sum().backward()
+    assert_close(xg.grad, xr.grad, 1e-4, "dx")
+    assert_close(gg.grad, gr.grad, 1e-4, "dgamma")
+    assert_close(bg.grad, br.grad, 1e-4, "dbeta")
