@@ -42,6 +42,13 @@ def shard_units(n_units: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_units, world))
 
 
+def _aligned_offsets(sizes: Sequence[int], align: int = 4) -> List[int]:
+    offs = [0]
+    for k in sizes:
+        offs.append(offs[-1] + (k + align - 1) // align * align)
+    return offs
+
+
 class FlatGradBuffer:
     """All gradients of `params` in one contiguous fp32 buffer (the all-reduce message).
 
@@ -59,20 +66,21 @@ class FlatGradBuffer:
             raise ValueError("no trainable parameters")
         dev = self.params[0].device
         self.sizes = [p.numel() for p in self.params]
-        n = sum(self.sizes)
+        # every slot starts on a 16-byte boundary: the HIP kernels read parameters / gradients as float4
+        self.offsets = _aligned_offsets(self.sizes)
+        n = self.offsets[-1]
         self.views = views
         for p in self.params:
             if p.dtype != torch.float32 or p.device != dev:
                 raise ValueError("FlatGradBuffer: fp32 parameters on one device expected")
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._pad = torch.zeros(4, dtype=torch.float32, device=dev)
         if views:
             self._assign_views()
 
     def _assign_views(self) -> None:
-        o = 0
-        for p, k in zip(self.params, self.sizes):
+        for p, k, o in zip(self.params, self.sizes, self.offsets):
             p.grad = self.flat[o:o + k].view_as(p)
-            o += k
 
     def zero(self) -> None:
         if self.views:
@@ -87,7 +95,11 @@ class FlatGradBuffer:
         if self.views or getattr(self, "_packed", False):
             return
         self._packed = True
-        parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
+        parts = []
+        for p, k, o, o_next in zip(self.params, self.sizes, self.offsets, self.offsets[1:]):
+            parts.append((p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1))
+            if o_next - o > k:
+                parts.append(self._pad[: o_next - o - k])
         torch.cat(parts, out=self.flat)
         self._assign_views()
 
@@ -118,11 +130,10 @@ class FlatAdamW:
         self.grads = grads
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         dev = self.params[0].device
-        self.flat = torch.cat([p.detach().reshape(-1) for p in self.params]).to(dev)
-        o = 0
-        for p in self.params:
+        self.flat = torch.zeros(grads.offsets[-1], dtype=torch.float32, device=dev)       # same 16-byte-aligned layout
+        for p, o in zip(self.params, grads.offsets):
+            self.flat[o:o + p.numel()] = p.detach().reshape(-1)
             p.data = self.flat[o:o + p.numel()].view_as(p)
-            o += p.numel()
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
 

@@ -31,6 +31,11 @@ def advance_rng(device) -> None:
     rng_state(device)[1] += 1
 
 
+def _al16(t: torch.Tensor) -> torch.Tensor:
+    """Parameters can be views into a flat optimizer buffer at any element offset; the kernel reads float4."""
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
 class _NormAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, p, flags, call_id):
@@ -43,7 +48,7 @@ class _NormAct(torch.autograd.Function):
         mean = torch.empty((max(n, 1),), dtype=torch.float32, device=dev)
         rstd = torch.empty((max(n, 1),), dtype=torch.float32, device=dev)
         rng = rng_state(dev) if p > 0 else None
-        gamma, beta = gamma.contiguous(), beta.contiguous()
+        gamma, beta = _al16(gamma.contiguous()), _al16(beta.contiguous())
         G = gamma.shape[0] if gamma.dim() == 2 else 1
         _lib.check(lib.agnn_norm_act_fwd_f32(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), G, n, H, float(eps), float(p),
                                              int(flags), _lib.ptr(rng), int(call_id), y.data_ptr(), y.stride(0), mean.data_ptr(),
