@@ -16,6 +16,7 @@ import torch.nn.functional as F
 from . import _lib
 from .encoders import TrimPlan, _HybridMixin
 from .graph import Csr, HeteroIndex, hetero_index
+from .linear import linear
 
 EdgeType = Tuple[str, str, str]
 
@@ -189,38 +190,39 @@ class HGTConv(nn.Module):
         heads, H = self.heads, self.out_channels
         D = H // heads
         n_of = {t: (n_keep[t] if n_keep is not None else int(x.shape[0])) for t, x in x_dict.items()}
-        kqv = {t: self.kqv_lin.lins[t](x[:n_of[t]]) for t, x in x_dict.items()}
-        k = {t: v[:, :H] for t, v in kqv.items()}
-        q = {t: v[:, H:2 * H] for t, v in kqv.items()}
-        v = {t: v[:, 2 * H:] for t, v in kqv.items()}
+        # k, q, v as three projections with row-slices of the fused kqv weight: slicing a [3H, in] weight is free, while
+        # slicing the [N, 3H] activation makes autograd materialise three zero-filled [N, 3H] gradients and add them
+        k, q, v = {}, {}, {}
+        for t, x in x_dict.items():
+            lin = self.kqv_lin.lins[t]
+            xt = x[:n_of[t]]
+            k[t] = linear(xt, lin.weight[:H], lin.bias[:H])
+            q[t] = linear(xt, lin.weight[H:2 * H], lin.bias[H:2 * H])
+            v[t] = linear(xt, lin.weight[2 * H:], lin.bias[2 * H:])
         by_dst: Dict[str, List[Tuple[int, EdgeType]]] = {}
         for e_idx, et in enumerate(self.edge_types):
             s, _, d = et
             if et in index.fwd and s in x_dict and d in x_dict:
                 by_dst.setdefault(d, []).append((e_idx, et))
-        # Relation transforms k' = k A_r^k, v' = v A_r^v: the per-(relation, head) D x D matrices of all relations that
-        # leave one source type are laid out as ONE block-diagonal [H, R_s*H] weight, so every source type needs one
-        # GEMM for K' and one for V' (and two well-shaped GEMMs for their weight gradients) instead of 2*R_s batched
-        # 64x64 GEMMs whose weight gradients have K = N and a 64 x 64 output.
-        by_src: Dict[str, List[int]] = {}
-        used = [e_idx for rels in by_dst.values() for e_idx, _ in rels]
-        for e_idx in used:
-            by_src.setdefault(self.edge_types[e_idx][0], []).append(e_idx)
+        # Relation transforms k' = k A_r^k, v' = v A_r^v: the heads' D x D matrices of one relation are laid out as one
+        # block-diagonal [H, H] weight (one scatter for all relations), so each relation is a plain [N_s, H] x [H, H] GEMM
+        # with a well-shaped weight gradient, instead of batched 64 x 64 GEMMs whose weight gradients have K = N.
+        used = sorted({e_idx for rels in by_dst.values() for e_idx, _ in rels})
         kv_of: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
-        ar = torch.arange(heads, device=next(iter(x_dict.values())).device)
-        for s, e_list in by_src.items():
-            Rs = len(e_list)
-            sel = _index_tensor(tuple(e_list), ar.device)
+        if used:
+            dev = next(iter(x_dict.values())).device
+            ar = torch.arange(heads, device=dev)
+            sel = _index_tensor(tuple(used), dev)
 
-            def big(weight):
-                w4 = weight.view(len(self.edge_types), heads, D, D).index_select(0, sel)      # [Rs, heads, D, D]
-                wb = w4.new_zeros(heads, D, Rs, heads, D)
-                wb[ar, :, :, ar, :] = w4.permute(1, 2, 0, 3)                                # block (h, r): A_r,h
-                return wb.view(H, Rs * H)
-            k_all = k[s] @ big(self.k_rel.weight)                                           # [N_s, Rs*H]
-            v_all = v[s] @ big(self.v_rel.weight)
-            for i, e_idx in enumerate(e_list):
-                kv_of[e_idx] = (k_all[:, i * H:(i + 1) * H], v_all[:, i * H:(i + 1) * H])
+            def dense(weight):
+                w4 = weight.view(len(self.edge_types), heads, D, D).index_select(0, sel)      # [R, heads, D, D]
+                wb = w4.new_zeros(len(used), heads, D, heads, D)
+                wb[:, ar, :, ar, :] = w4.permute(1, 0, 2, 3)                                # block (h, h) of relation r
+                return wb.view(len(used), H, H)
+            Wk, Wv = dense(self.k_rel.weight), dense(self.v_rel.weight)
+            for i, e_idx in enumerate(used):
+                s_t = self.edge_types[e_idx][0]
+                kv_of[e_idx] = (linear(k[s_t], Wk[i].t()), linear(v[s_t], Wv[i].t()))
         out = {}
         for t, x in x_dict.items():
             n = n_of[t]
