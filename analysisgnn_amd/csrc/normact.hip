@@ -28,7 +28,7 @@ struct NaArgs {
   uint32_t flags;          // AGNN_NA_*
   const int64_t* rng;      // device [2]: seed, step
   uint32_t call_id;
-  int32_t n_groups;        // gamma / beta are [n_groups, H]; row r uses group r % n_groups (1 = plain LayerNorm)
+  int32_t seg;             // statistics over segments of `seg` floats of the row (seg == H: plain LayerNorm)
 };
 
 __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
@@ -59,6 +59,11 @@ __device__ __forceinline__ float wsum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// sum over the gl (power of two <= 64) adjacent lanes that hold one segment
+__device__ __forceinline__ float gsum(float v, int gl) {
+  for (int o = 1; o < gl; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
 
 template <int CH>
 __global__ __launch_bounds__(256) void k_na_fwd(NaArgs a, float* __restrict__ y, int64_t ld_y, float* __restrict__ mean_out,
@@ -78,26 +83,47 @@ __global__ __launch_bounds__(256) void k_na_fwd(NaArgs a, float* __restrict__ y,
     if (pre) { v[c].x = fmaxf(v[c].x, 0.f); v[c].y = fmaxf(v[c].y, 0.f); v[c].z = fmaxf(v[c].z, 0.f); v[c].w = fmaxf(v[c].w, 0.f); }
     s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
   }
-  const float invH = 1.f / static_cast<float>(a.H);
-  const float mean = wsum(s) * invH;
-  float q = 0.f;
+  // statistics: one segment = the whole row (plain LayerNorm) or `seg` floats held by seg/4 adjacent lanes of one chunk
+  const bool whole = a.seg >= a.H;
+  const int gl = a.seg >> 2;
+  const int nseg = whole ? 1 : a.H / a.seg;
+  const float invS = 1.f / static_cast<float>(whole ? a.H : a.seg);
+  float mean[CH], rstd[CH];
+  if (whole) {
+    const float m = wsum(s) * invS;
+    float q = 0.f;
 #pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    if (!on[c]) continue;
-    const float dx = v[c].x - mean, dy = v[c].y - mean, dz = v[c].z - mean, dw = v[c].w - mean;
-    q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    for (int c = 0; c < CH; ++c) {
+      if (!on[c]) continue;
+      const float dx = v[c].x - m, dy = v[c].y - m, dz = v[c].z - m, dw = v[c].w - m;
+      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+    const float r = 1.f / sqrtf(wsum(q) * invS + a.eps);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) { mean[c] = m; rstd[c] = r; }
+    if (lane == 0) { mean_out[row] = m; rstd_out[row] = r; }
+  } else {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const float sc = (v[c].x + v[c].y) + (v[c].z + v[c].w);
+      const float m = gsum(sc, gl) * invS;
+      const float dx = v[c].x - m, dy = v[c].y - m, dz = v[c].z - m, dw = v[c].w - m;
+      const float q = on[c] ? (dx * dx + dy * dy) + (dz * dz + dw * dw) : 0.f;
+      const float r = 1.f / sqrtf(gsum(q, gl) * invS + a.eps);
+      mean[c] = m;
+      rstd[c] = r;
+      const int f = c * 256 + lane * 4;
+      if (on[c] && (f % a.seg) == 0) { mean_out[row * nseg + f / a.seg] = m; rstd_out[row * nseg + f / a.seg] = r; }
+    }
   }
-  const float rstd = 1.f / sqrtf(wsum(q) * invH + a.eps);
-  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
   const float scale = drop ? 1.f / (1.f - a.p) : 1.f;
   float4* yp = reinterpret_cast<float4*>(y + row * ld_y);
-  const int64_t goff = (a.n_groups > 1 ? (row % a.n_groups) : 0) * static_cast<int64_t>(a.H);
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     if (!on[c]) continue;
-    const float4 g = reinterpret_cast<const float4*>(a.gamma + goff)[c * 64 + lane], b = reinterpret_cast<const float4*>(a.beta + goff)[c * 64 + lane];
-    float4 o = make_float4((v[c].x - mean) * rstd * g.x + b.x, (v[c].y - mean) * rstd * g.y + b.y,
-                           (v[c].z - mean) * rstd * g.z + b.z, (v[c].w - mean) * rstd * g.w + b.w);
+    const float4 g = reinterpret_cast<const float4*>(a.gamma)[c * 64 + lane], b = reinterpret_cast<const float4*>(a.beta)[c * 64 + lane];
+    float4 o = make_float4((v[c].x - mean[c]) * rstd[c] * g.x + b.x, (v[c].y - mean[c]) * rstd[c] * g.y + b.y,
+                           (v[c].z - mean[c]) * rstd[c] * g.z + b.z, (v[c].w - mean[c]) * rstd[c] * g.w + b.w);
     if (post) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
     if (drop) {
       const float4 m = keep_mask(a, row, c * 64 + lane, scale);
@@ -117,27 +143,31 @@ __global__ __launch_bounds__(256) void k_na_bwd(NaArgs a, const float* __restric
   const int n_waves = gridDim.x * 4;
   const bool pre = a.flags & AGNN_NA_PRE_RELU, post = a.flags & AGNN_NA_POST_RELU, drop = a.p > 0.f;
   const float scale = drop ? 1.f / (1.f - a.p) : 1.f;
-  const float invH = 1.f / static_cast<float>(a.H);
   bool on[CH];
   float4 gm[CH], bt[CH], dg[CH], db[CH];
-  // the launch makes n_waves a multiple of n_groups, so every row of this wave belongs to group wave_g % n_groups
-  const int64_t goff = (a.n_groups > 1 ? (wave_g % a.n_groups) : 0) * static_cast<int64_t>(a.H);
+  const bool whole = a.seg >= a.H;
+  const int gl = a.seg >> 2;
+  const int nseg = whole ? 1 : a.H / a.seg;
+  const float invS = 1.f / static_cast<float>(whole ? a.H : a.seg);
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     on[c] = (c * 256 + lane * 4) < a.H;
-    gm[c] = on[c] ? reinterpret_cast<const float4*>(a.gamma + goff)[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-    bt[c] = on[c] ? reinterpret_cast<const float4*>(a.beta + goff)[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    gm[c] = on[c] ? reinterpret_cast<const float4*>(a.gamma)[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    bt[c] = on[c] ? reinterpret_cast<const float4*>(a.beta)[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
     dg[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     db[c] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   for (int64_t row = wave_g; row < a.n; row += n_waves) {
-    const float mean = mean_in[row], rstd = rstd_in[row];
     const float4* xp = reinterpret_cast<const float4*>(a.x + row * a.ld_x);
     const float4* gp = reinterpret_cast<const float4*>(dy + row * ld_dy);
     float4 xr[CH], xh[CH], gx[CH];
+    float rs[CH], p1[CH], p2[CH];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
+      const int sidx = whole ? 0 : (on[c] ? (c * 256 + lane * 4) / a.seg : 0);
+      const float mean = mean_in[row * nseg + sidx], rstd = rstd_in[row * nseg + sidx];
+      rs[c] = rstd;
       xr[c] = on[c] ? xp[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
       float4 g = on[c] ? gp[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
       float4 v = xr[c];
@@ -157,16 +187,26 @@ __global__ __launch_bounds__(256) void k_na_bwd(NaArgs a, const float* __restric
       dg[c].x += g.x * xh[c].x; dg[c].y += g.y * xh[c].y; dg[c].z += g.z * xh[c].z; dg[c].w += g.w * xh[c].w;
       db[c].x += g.x; db[c].y += g.y; db[c].z += g.z; db[c].w += g.w;
       gx[c] = make_float4(g.x * gm[c].x, g.y * gm[c].y, g.z * gm[c].z, g.w * gm[c].w);           // d xhat
-      s1 += (gx[c].x + gx[c].y) + (gx[c].z + gx[c].w);
-      s2 += (gx[c].x * xh[c].x + gx[c].y * xh[c].y) + (gx[c].z * xh[c].z + gx[c].w * xh[c].w);
+      p1[c] = (gx[c].x + gx[c].y) + (gx[c].z + gx[c].w);
+      p2[c] = (gx[c].x * xh[c].x + gx[c].y * xh[c].y) + (gx[c].z * xh[c].z + gx[c].w * xh[c].w);
+      s1 += p1[c];
+      s2 += p2[c];
     }
-    const float m1 = wsum(s1) * invH, m2 = wsum(s2) * invH;
+    float m1[CH], m2[CH];
+    if (whole) {
+      const float t1 = wsum(s1) * invS, t2 = wsum(s2) * invS;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) { m1[c] = t1; m2[c] = t2; }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CH; ++c) { m1[c] = gsum(p1[c], gl) * invS; m2[c] = gsum(p2[c], gl) * invS; }
+    }
     float4* op = reinterpret_cast<float4*>(dx + row * ld_dx);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       if (!on[c]) continue;
-      float4 o = make_float4(rstd * (gx[c].x - m1 - xh[c].x * m2), rstd * (gx[c].y - m1 - xh[c].y * m2),
-                             rstd * (gx[c].z - m1 - xh[c].z * m2), rstd * (gx[c].w - m1 - xh[c].w * m2));
+      float4 o = make_float4(rs[c] * (gx[c].x - m1[c] - xh[c].x * m2[c]), rs[c] * (gx[c].y - m1[c] - xh[c].y * m2[c]),
+                             rs[c] * (gx[c].z - m1[c] - xh[c].z * m2[c]), rs[c] * (gx[c].w - m1[c] - xh[c].w * m2[c]));
       if (pre) {
         if (xr[c].x <= 0.f) o.x = 0.f;
         if (xr[c].y <= 0.f) o.y = 0.f;
@@ -186,32 +226,36 @@ __global__ __launch_bounds__(256) void k_na_bwd(NaArgs a, const float* __restric
   }
 }
 
-// dgamma[g][j] | dbeta[g][j] = sum over waves w with w % G == g of part[w][j | H + j].  Block = 32 columns x 8 partial sums.
-__global__ __launch_bounds__(256) void k_na_colsum(const float* __restrict__ part, int n_waves, int width, int G, float* __restrict__ dgamma,
+// dgamma[j] | dbeta[j] = sum over waves of part[w][j | H + j].  Block = 32 columns x 8 partial sums (fixed order).
+__global__ __launch_bounds__(256) void k_na_colsum(const float* __restrict__ part, int n_waves, int width, float* __restrict__ dgamma,
                                                    float* __restrict__ dbeta, int H) {
   __shared__ float sm[8][32];
   const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int j = blockIdx.x * 32 + col;
-  const int g = blockIdx.y;
   float s = 0.f;
   if (j < width)
-    for (int w = g + grp * G; w < n_waves; w += 8 * G) s += part[static_cast<int64_t>(w) * width + j];
+    for (int w = grp; w < n_waves; w += 8) s += part[static_cast<int64_t>(w) * width + j];
   sm[grp][col] = s;
   __syncthreads();
   if (grp == 0 && j < width) {
     float t = sm[0][col];
 #pragma unroll
     for (int k = 1; k < 8; ++k) t += sm[k][col];
-    if (j < H) dgamma[static_cast<int64_t>(g) * H + j] = t; else dbeta[static_cast<int64_t>(g) * H + j - H] = t;
+    if (j < H) dgamma[j] = t; else dbeta[j - H] = t;
   }
 }
 
-constexpr int kBwdBlocks = 256;     // up to 1024 waves: partial slab = 1024 * 2H floats
+constexpr int kBwdBlocks = 256;     // 1024 waves: partial slab = 1024 * 2H floats
 
-int na_check(const char* who, const void* x, int64_t ld_x, const void* gamma, const void* beta, int64_t n, int32_t H, float p,
-             const void* rng) {
+int na_check(const char* who, const void* x, int64_t ld_x, const void* gamma, const void* beta, int64_t n, int32_t H, int32_t seg,
+             float p, const void* rng) {
   using namespace agnn;
-  if (n < 0 || H <= 0 || (H & 3) || H > 1024) return fail(AGNN_EINVAL, "%s: H=%d must be a multiple of 4 in [4,1024], n=%lld", who, H, (long long)n);
+  if (n < 0 || H <= 0 || (H & 3) || H > 2048) return fail(AGNN_EINVAL, "%s: H=%d must be a multiple of 4 in [4,2048], n=%lld", who, H, (long long)n);
+  if (seg != H) {
+    const int gl = seg / 4;
+    if (seg <= 0 || (seg & 3) || 256 % seg != 0 || H % seg != 0 || (gl & (gl - 1)))
+      return fail(AGNN_EINVAL, "%s: segment %d must be 4*2^k, divide 256 and divide H=%d", who, seg, H);
+  }
   if (p < 0.f || p >= 1.f) return fail(AGNN_EINVAL, "%s: dropout p=%f", who, p);
   if (n == 0) return 1;
   if (!x || !gamma || !beta) return fail(AGNN_EINVAL, "%s: null argument", who);
@@ -222,48 +266,48 @@ int na_check(const char* who, const void* x, int64_t ld_x, const void* gamma, co
 
 }  // namespace
 
-extern "C" size_t agnn_norm_act_workspace_bytes(int32_t H) { return (static_cast<size_t>(kBwdBlocks) * 4 + 1024) * 2 * static_cast<size_t>(H > 0 ? H : 0) * sizeof(float); }
+extern "C" size_t agnn_norm_act_workspace_bytes(int32_t H) { return static_cast<size_t>(kBwdBlocks) * 4 * 2 * static_cast<size_t>(H > 0 ? H : 0) * sizeof(float); }
 
-extern "C" int agnn_norm_act_fwd_f32(const float* x, int64_t ld_x, const float* gamma, const float* beta, int32_t n_groups, int64_t n,
+#define AGNN_NA_DISPATCH(KERN, ...)                                                          \
+  do {                                                                                       \
+    if (H <= 256) hipLaunchKernelGGL(KERN<1>, grid, block, 0, s, __VA_ARGS__);               \
+    else if (H <= 512) hipLaunchKernelGGL(KERN<2>, grid, block, 0, s, __VA_ARGS__);          \
+    else if (H <= 1024) hipLaunchKernelGGL(KERN<4>, grid, block, 0, s, __VA_ARGS__);         \
+    else if (H <= 1536) hipLaunchKernelGGL(KERN<6>, grid, block, 0, s, __VA_ARGS__);         \
+    else hipLaunchKernelGGL(KERN<8>, grid, block, 0, s, __VA_ARGS__);                        \
+  } while (0)
+
+extern "C" int agnn_norm_act_fwd_f32(const float* x, int64_t ld_x, const float* gamma, const float* beta, int32_t seg, int64_t n,
                                      int32_t H, float eps, float p, uint32_t flags, const int64_t* rng_state, uint32_t call_id,
                                      float* y, int64_t ld_y, float* mean, float* rstd, agnn_stream_t stream_) {
   using namespace agnn;
-  if (int rc = na_check("norm_act_fwd", x, ld_x, gamma, beta, n, H, p, rng_state)) return rc > 0 ? AGNN_OK : rc;
+  if (seg <= 0 || seg > H) seg = H;
+  if (int rc = na_check("norm_act_fwd", x, ld_x, gamma, beta, n, H, seg, p, rng_state)) return rc > 0 ? AGNN_OK : rc;
   if (!y || !mean || !rstd || !aligned16(y) || (ld_y & 3) || ld_y < H) return fail(AGNN_EALIGN, "norm_act_fwd: output misaligned");
-  if (n_groups < 1 || n_groups > 256) return fail(AGNN_EINVAL, "norm_act_fwd: n_groups=%d", n_groups);
-  NaArgs a{x, ld_x, gamma, beta, n, H, eps, p, flags, rng_state, call_id, n_groups};
+  NaArgs a{x, ld_x, gamma, beta, n, H, eps, p, flags, rng_state, call_id, seg};
   const dim3 grid(static_cast<unsigned>((n + 3) / 4)), block(256);
   hipStream_t s = static_cast<hipStream_t>(stream_);
-  if (H <= 256) hipLaunchKernelGGL(k_na_fwd<1>, grid, block, 0, s, a, y, ld_y, mean, rstd);
-  else if (H <= 512) hipLaunchKernelGGL(k_na_fwd<2>, grid, block, 0, s, a, y, ld_y, mean, rstd);
-  else hipLaunchKernelGGL(k_na_fwd<4>, grid, block, 0, s, a, y, ld_y, mean, rstd);
+  AGNN_NA_DISPATCH(k_na_fwd, a, y, ld_y, mean, rstd);
   return check_launch("norm_act_fwd");
 }
 
-extern "C" int agnn_norm_act_bwd_f32(const float* x, int64_t ld_x, const float* gamma, const float* beta, int32_t n_groups, int64_t n,
+extern "C" int agnn_norm_act_bwd_f32(const float* x, int64_t ld_x, const float* gamma, const float* beta, int32_t seg, int64_t n,
                                      int32_t H, float eps, float p, uint32_t flags, const int64_t* rng_state, uint32_t call_id,
                                      const float* dy, int64_t ld_dy, const float* mean, const float* rstd, float* dx, int64_t ld_dx,
                                      float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, agnn_stream_t stream_) {
   using namespace agnn;
-  if (int rc = na_check("norm_act_bwd", x, ld_x, gamma, beta, n, H, p, rng_state)) return rc > 0 ? AGNN_OK : rc;
+  if (seg <= 0 || seg > H) seg = H;
+  if (int rc = na_check("norm_act_bwd", x, ld_x, gamma, beta, n, H, seg, p, rng_state)) return rc > 0 ? AGNN_OK : rc;
   if (!dy || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace) return fail(AGNN_EINVAL, "norm_act_bwd: null argument");
   if (!aligned16(dy) || !aligned16(dx) || !aligned16(workspace) || (ld_dy & 3) || (ld_dx & 3)) return fail(AGNN_EALIGN, "norm_act_bwd: misaligned");
   if (workspace_bytes < agnn_norm_act_workspace_bytes(H)) return fail(AGNN_ENOMEM, "norm_act_bwd: workspace too small");
-  if (n_groups < 1 || n_groups > 256) return fail(AGNN_EINVAL, "norm_act_bwd: n_groups=%d", n_groups);
-  NaArgs a{x, ld_x, gamma, beta, n, H, eps, p, flags, rng_state, call_id, n_groups};
+  NaArgs a{x, ld_x, gamma, beta, n, H, eps, p, flags, rng_state, call_id, seg};
   float* part = static_cast<float*>(workspace);
   hipStream_t s = static_cast<hipStream_t>(stream_);
-  // number of waves: a multiple of 4 (waves per block) and of n_groups, at most kBwdBlocks * 4
-  int lcm = n_groups;
-  while (lcm % 4) lcm += n_groups;
-  int n_waves = (kBwdBlocks * 4 / lcm) * lcm;
-  if (n_waves < lcm) n_waves = lcm;
-  const dim3 grid(n_waves / 4), block(256);
-  if (H <= 256) hipLaunchKernelGGL(k_na_bwd<1>, grid, block, 0, s, a, dy, ld_dy, mean, rstd, dx, ld_dx, part);
-  else if (H <= 512) hipLaunchKernelGGL(k_na_bwd<2>, grid, block, 0, s, a, dy, ld_dy, mean, rstd, dx, ld_dx, part);
-  else hipLaunchKernelGGL(k_na_bwd<4>, grid, block, 0, s, a, dy, ld_dy, mean, rstd, dx, ld_dx, part);
+  const dim3 grid(kBwdBlocks), block(256);
+  AGNN_NA_DISPATCH(k_na_bwd, a, dy, ld_dy, mean, rstd, dx, ld_dx, part);
   if (int rc = check_launch("norm_act_bwd")) return rc;
   const int width = 2 * H;
-  hipLaunchKernelGGL(k_na_colsum, dim3((width + 31) / 32, n_groups), dim3(256), 0, s, part, n_waves, width, n_groups, dgamma, dbeta, H);
+  hipLaunchKernelGGL(k_na_colsum, dim3((width + 31) / 32), dim3(256), 0, s, part, kBwdBlocks * 4, width, dgamma, dbeta, H);
   return check_launch("norm_act_colsum");
 }

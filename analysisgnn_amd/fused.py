@@ -38,29 +38,29 @@ def _al16(t: torch.Tensor) -> torch.Tensor:
 
 class _NormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, p, flags, call_id):
-        """gamma / beta: [H] or [G, H] (row r of x uses group r % G)."""
+    def forward(ctx, x, gamma, beta, eps, p, flags, call_id, seg=0):
+        """x [n, H]; gamma / beta [H]; statistics over segments of `seg` floats (0 = the whole row)."""
         dev = _lib.require_gpu(x, gamma, beta)
         lib = _lib.load()
         x = x if (x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else x.contiguous()
         n, H = x.shape
         y = torch.empty((n, H), dtype=torch.float32, device=dev)
-        mean = torch.empty((max(n, 1),), dtype=torch.float32, device=dev)
-        rstd = torch.empty((max(n, 1),), dtype=torch.float32, device=dev)
+        seg = int(seg) if seg else H
+        mean = torch.empty((max(n, 1) * (H // seg),), dtype=torch.float32, device=dev)
+        rstd = torch.empty((max(n, 1) * (H // seg),), dtype=torch.float32, device=dev)
         rng = rng_state(dev) if p > 0 else None
         gamma, beta = _al16(gamma.contiguous()), _al16(beta.contiguous())
-        G = gamma.shape[0] if gamma.dim() == 2 else 1
-        _lib.check(lib.agnn_norm_act_fwd_f32(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), G, n, H, float(eps), float(p),
+        _lib.check(lib.agnn_norm_act_fwd_f32(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), seg, n, H, float(eps), float(p),
                                              int(flags), _lib.ptr(rng), int(call_id), y.data_ptr(), y.stride(0), mean.data_ptr(),
                                              rstd.data_ptr(), _lib.stream_ptr(dev)), "agnn_norm_act_fwd_f32")
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
-        ctx.cfg = (float(eps), float(p), int(flags), int(call_id))
+        ctx.cfg = (float(eps), float(p), int(flags), int(call_id), seg)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta, mean, rstd = ctx.saved_tensors
-        eps, p, flags, call_id = ctx.cfg
+        eps, p, flags, call_id, seg = ctx.cfg
         dev = dy.device
         lib = _lib.load()
         dy = dy if (dy.stride(1) == 1 and dy.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0) else dy.contiguous()
@@ -71,12 +71,11 @@ class _NormAct(torch.autograd.Function):
         nws = int(lib.agnn_norm_act_workspace_bytes(H))
         ws = torch.empty(nws, dtype=torch.uint8, device=dev)
         rng = rng_state(dev) if p > 0 else None
-        G = gamma.shape[0] if gamma.dim() == 2 else 1
-        _lib.check(lib.agnn_norm_act_bwd_f32(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), G, n, H, eps, p, flags,
+        _lib.check(lib.agnn_norm_act_bwd_f32(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), seg, n, H, eps, p, flags,
                                              _lib.ptr(rng), call_id, dy.data_ptr(), dy.stride(0), mean.data_ptr(), rstd.data_ptr(),
                                              dx.data_ptr(), dx.stride(0), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), nws,
                                              _lib.stream_ptr(dev)), "agnn_norm_act_bwd_f32")
-        return dx, dgamma, dbeta, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None
 
 
 def norm_act(x: torch.Tensor, ln: nn.LayerNorm, pre_relu: bool = False, post_relu: bool = False, p: float = 0.0,
@@ -98,12 +97,16 @@ def norm_act(x: torch.Tensor, ln: nn.LayerNorm, pre_relu: bool = False, post_rel
 
 def grouped_norm_act(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, pre_relu: bool = False) -> torch.Tensor:
     """x [N, G, H] -> LayerNorm over H with per-group affine gamma/beta [G, H] (optionally ReLU first): the G task heads'
-    `ReLU -> LayerNorm` of one note in one launch (models/analysis.py:488-493)."""
+    `ReLU -> LayerNorm` of one note in ONE pass over the [N, G*H] row (segmented statistics, models/analysis.py:488-493)."""
     N, G, H = x.shape
-    if not (ENABLED and x.is_cuda and x.dtype == torch.float32 and H % 4 == 0 and H <= 1024 and G <= 256):
+    W = G * H
+    gl = H // 4
+    ok = (ENABLED and x.is_cuda and x.dtype == torch.float32 and H % 4 == 0 and 256 % H == 0 and (gl & (gl - 1)) == 0 and W <= 2048)
+    if not ok:
         y = F.relu(x) if pre_relu else x
         return F.layer_norm(y, (H,), None, None, eps) * gamma + beta
-    y = _NormAct.apply(x.reshape(N * G, H), gamma, beta, eps, 0.0, PRE_RELU if pre_relu else 0, next(_CALL_IDS) & 0xFFFFFFFF)
+    y = _NormAct.apply(x.reshape(N, W), gamma.reshape(W), beta.reshape(W), eps, 0.0, PRE_RELU if pre_relu else 0,
+                       next(_CALL_IDS) & 0xFFFFFFFF, H)
     return y.view(N, G, H)
 
 

@@ -218,16 +218,17 @@ int agnn_gated_bwd_src_f32(const agnn_gated_t* g /* (host) */, const float* ds, 
  * backward recomputes the ReLU masks from x and the dropout mask from the counter-based generator:
  * Philox-4x32-10(seed = rng_state[0], counter = (element, call_id, step = rng_state[1])), rng_state a DEVICE
  * int64[2] so a captured graph draws new masks when the caller bumps the step between replays.
- * gamma / beta (and dgamma / dbeta) are [n_groups, H]: row r uses group r % n_groups — n_groups = 1 is a plain
- * LayerNorm, n_groups = T normalises the T task-head activations of one note, stored as T consecutive rows.
+ * `seg`: the statistics are taken over segments of `seg` consecutive floats of a row (seg = H: plain LayerNorm;
+ * seg = 64 with H = T*64: the T task heads' LayerNorms of one note in one pass, gamma / beta being the [T*64]
+ * concatenation of the per-task affines).  seg must be 4*2^k, divide 256 and divide H.  mean / rstd: [n, H/seg].
  * ------------------------------------------------------------------------------------------ */
 #define AGNN_NA_PRE_RELU  1u
 #define AGNN_NA_POST_RELU 2u
 size_t agnn_norm_act_workspace_bytes(int32_t H);
-int agnn_norm_act_fwd_f32(const float* x, int64_t ld_x, const float* gamma, const float* beta, int32_t n_groups,
+int agnn_norm_act_fwd_f32(const float* x, int64_t ld_x, const float* gamma, const float* beta, int32_t seg,
                           int64_t n, int32_t H, float eps, float p, uint32_t flags, const int64_t* rng_state, uint32_t call_id, float* y,
                           int64_t ld_y, float* mean, float* rstd, agnn_stream_t stream);
-int agnn_norm_act_bwd_f32(const float* x, int64_t ld_x, const float* gamma, const float* beta, int32_t n_groups,
+int agnn_norm_act_bwd_f32(const float* x, int64_t ld_x, const float* gamma, const float* beta, int32_t seg,
                           int64_t n, int32_t H, float eps, float p, uint32_t flags, const int64_t* rng_state, uint32_t call_id,
                           const float* dy, int64_t ld_dy, const float* mean, const float* rstd, float* dx,
                           int64_t ld_dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
