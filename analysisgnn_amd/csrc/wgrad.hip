@@ -47,43 +47,75 @@ __global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
 
   f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
   float bs0 = 0.f, bs1 = 0.f;
-  const float* dyp = a.dy + ocol;
-  const float* xp = a.x + icol;
-  // Rows are consumed two at a time (one MFMA k-step); CH k-steps are fetched together, one chunk ahead of the
-  // MFMAs that use them, so ~2*CH independent 8-byte loads per lane are in flight while 4*CH MFMAs (64 cycles
-  // each) run: with one k-step of prefetch the matrix pipe sat idle behind every HBM/L2 round trip.
-  constexpr int CH = 8;
-  float2 av[CH], bv[CH], an[CH], bn[CH];
-  auto fetch = [&](int base, float2* ao, float2* bo) {
+  // Loads are unconditional so the loop stays straight-line code and the compiler can wait on "all but the last two
+  // chunks" (s_waitcnt vmcnt(N)) instead of draining the queue behind a branch: lanes whose columns lie past the
+  // matrix read column 0 (their accumulator rows / columns are never read back), rows past the end of the matrix
+  // are clamped, and rows past the end of the SLICE only occur in the last chunks, which multiply by a 0/1 mask.
+  // Addresses: a per-slice base pointer (uniform -> SGPR pair) plus a 32-bit byte offset per lane (the C-ABI entry
+  // point checks rows_per_slice * ld * 4 < 2^32), i.e. the "saddr + voffset" form: one multiply-add per load.
+  const float* dy_s = a.dy + static_cast<int64_t>(r0) * a.ld_dy;
+  const float* x_s = a.x + static_cast<int64_t>(r0) * a.ld_x;
+  const uint32_t ldb_dy = static_cast<uint32_t>(a.ld_dy) * 4u, ldb_x = static_cast<uint32_t>(a.ld_x) * 4u;
+  const uint32_t cb_dy = (o_ok ? ocol : 0) * 4u, cb_x = (i_ok ? icol : 0) * 4u;
+  const int rel_last = a.n - 1 - r0;
+  constexpr int CH = 8;                              // k-steps (row pairs) per chunk
+  constexpr int STEP = 2 * CH;                       // rows per chunk
+  // Three register stages in rotation: the loads of chunk c+2 are issued before the MFMAs of chunk c, so two whole
+  // chunks of matrix work (2 x 32 MFMAs = 4096 cycles of one wave) cover an L2/HBM round trip even when a SIMD
+  // holds a single wave (256 x 256 outputs give one workgroup per CU).  The scheduling barrier after each fetch
+  // keeps the compiler from hoisting the bias-sum adds of a chunk right behind its loads (which drained the queue).
+  float2 a0[CH], b0[CH], a1[CH], b1[CH], a2[CH], b2[CH];
+  auto fetch = [&](int chunk, float2* ao, float2* bo) {
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
-      const int n = base + 2 * u + kk;
-      ao[u] = make_float2(0.f, 0.f);
-      bo[u] = make_float2(0.f, 0.f);
-      if (n < r1) {
-        if (o_ok) ao[u] = *reinterpret_cast<const float2*>(dyp + static_cast<int64_t>(n) * a.ld_dy);
-        if (i_ok) bo[u] = *reinterpret_cast<const float2*>(xp + static_cast<int64_t>(n) * a.ld_x);
-      }
+      const uint32_t rel = static_cast<uint32_t>(min(chunk * STEP + 2 * u + kk, rel_last));
+      ao[u] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(dy_s) + (rel * ldb_dy + cb_dy));
+      bo[u] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(x_s) + (rel * ldb_x + cb_x));
     }
+    __builtin_amdgcn_sched_barrier(0);
   };
-  fetch(r0, av, bv);
-  for (int base = r0; base < r1; base += 2 * CH) {
-    if (base + 2 * CH < r1) fetch(base + 2 * CH, an, bn);
+  auto mma = [&](const float2* av, const float2* bv) {
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
       acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].x, acc00, 0, 0, 0);
       acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].y, acc01, 0, 0, 0);
       acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].x, acc10, 0, 0, 0);
       acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].y, acc11, 0, 0, 0);
-      bs0 += av[u].x;
-      bs1 += av[u].y;
+      // volatile asm: pins the bias-sum adds to this phase (plain adds were hoisted behind the loads of the chunk)
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(bs0) : "v"(av[u].x));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(bs1) : "v"(av[u].y));
     }
+  };
+  auto mma_tail = [&](int chunk, const float2* av, const float2* bv) {     // rows >= r1 contribute nothing
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
-      av[u] = an[u];
-      bv[u] = bn[u];
+      const float m = (r0 + chunk * STEP + 2 * u + kk < r1) ? 1.f : 0.f;
+      const float ax = av[u].x * m, ay = av[u].y * m;
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bv[u].x, acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bv[u].y, acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(ay, bv[u].x, acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(ay, bv[u].y, acc11, 0, 0, 0);
+      bs0 += ax;
+      bs1 += ay;
     }
+  };
+  const int nfull = (r1 - r0) / STEP;                // chunks that lie entirely inside the slice
+  const int nchunks = (r1 - r0 + STEP - 1) / STEP;
+  fetch(0, a0, b0);
+  fetch(1, a1, b1);
+  int c = 0;
+  for (; c + 3 <= nfull; c += 3) {
+    fetch(c + 2, a2, b2);
+    mma(a0, b0);
+    fetch(c + 3, a0, b0);
+    mma(a1, b1);
+    fetch(c + 4, a1, b1);
+    mma(a2, b2);
   }
+  fetch(c + 2, a2, b2);
+  if (c < nchunks) mma_tail(c, a0, b0);
+  if (c + 1 < nchunks) mma_tail(c + 1, a1, b1);
+  if (c + 2 < nchunks) mma_tail(c + 2, a2, b2);
   // C/D layout of 32x32 MFMA: lane l, register r -> row i = (r&3) + 8*(r>>2) + 4*(l>>5), column j = l&31
   float* slab = a.slab + (static_cast<int64_t>(slice) * a.out_pad) * a.in_pad;
   const int ob = to * 128 + wm * 64, ib = ti * 128 + wn * 64;
@@ -139,10 +171,26 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     __syncthreads();
   }
   if (db != nullptr) {
-    for (int64_t o = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; o < out_f; o += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-      float s = 0.f;
-      for (int k = 0; k < S; ++k) s += slab_b[static_cast<int64_t>(k) * out_pad + o];
-      db[o] = s;
+    // same 32 x 8 decomposition for the bias slabs (a serial walk over S slabs cost ~19 us of load latency)
+    const int half_out = out_f >> 1;
+    for (int e0 = blockIdx.x * 32; e0 < half_out; e0 += gridDim.x * 32) {
+      const int e = e0 + col;
+      float2 s = make_float2(0.f, 0.f);
+      if (e < half_out)
+        for (int k = sg; k < S; k += 8) {
+          const float2 v = *reinterpret_cast<const float2*>(slab_b + static_cast<int64_t>(k) * out_pad + 2 * e);
+          s.x += v.x;
+          s.y += v.y;
+        }
+      part[sg][col] = s;
+      __syncthreads();
+      if (sg == 0 && e < half_out) {
+        float2 t = part[0][col];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) { t.x += part[g][col].x; t.y += part[g][col].y; }
+        *reinterpret_cast<float2*>(db + 2 * e) = t;
+      }
+      __syncthreads();
     }
   }
 }
@@ -191,6 +239,8 @@ extern "C" int agnn_wgrad_f32(const float* dy, int64_t ld_dy, const float* x, in
   const size_t need = agnn_wgrad_workspace_bytes(n, out_f, in_f);
   if (workspace_bytes < need) return fail(AGNN_ENOMEM, "wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
   const Plan p = make_plan(n, out_f, in_f);
+  if ((static_cast<int64_t>(p.rows_per_slice) + 128) * (ld_dy > ld_x ? ld_dy : ld_x) * 4 >= (int64_t{1} << 32))
+    return fail(AGNN_EINVAL, "wgrad: a row slice (%d rows x ld) exceeds the kernel's 32-bit byte offsets", p.rows_per_slice);
   char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t{255});
   float* slab = reinterpret_cast<float*>(ws);
   float* slab_b = slab + static_cast<size_t>(p.S) * p.out_pad * p.in_pad;

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 from . import _lib
 
 MIN_ROWS = 2048          # below this the library GEMM is fine
-MAX_OUT_IN = 256 * 512   # above this output size the library's large-tile GEMM is as fast (measured: scripts/bench_wgrad.py)
+MAX_OUT_IN = 512 * 1024  # above this output size the library GEMM (large tiles, no slabs) is faster (scripts/bench_wgrad.py)
 ENABLED = True           # A/B switch for benchmarking
 
 

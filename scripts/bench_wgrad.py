@@ -6,6 +6,7 @@ sys.path.insert(0, ROOT)
 import torch
 from analysisgnn_amd import linear
 dev = "cuda:0"
+linear.MAX_OUT_IN = int(os.environ.get("AGNN_WGRAD_MAX", linear.MAX_OUT_IN))
 shapes = [(16000, 256, 256), (16000, 256, 1024), (16000, 768, 256), (16000, 384, 128), (16000, 1344, 128), (16000, 690, 1344),
           (16000, 128, 256), (16000, 256, 512), (16000, 128, 128)]
 for n, o, i in shapes:
