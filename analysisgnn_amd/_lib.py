@@ -79,6 +79,12 @@ SIGNATURES = {
     "agnn_wgrad_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "agnn_wgrad_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "agnn_gproj_fwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "agnn_gproj_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    "agnn_gproj_bwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_size_t, C.c_void_p]),
     "agnn_multitask_ce_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_float,
                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

@@ -1,0 +1,281 @@
+// Grouped projection: the last Linear(h2 -> C_t) of all T task heads as ONE launch per direction.
+//
+//   out[n, off_g + c] = b[off_g + c] + sum_k a[n, g*K + k] * w[off_g + c, k]        c < C_g = off_{g+1} - off_g
+//
+// The reference runs T = 21 separate nn.Linear(64, C_t) (analysisgnn/models/analysis.py:486-496, :546-548).  As one
+// library GEMM against the block-diagonal [sum C, T*64] weight it costs 21x the useful FLOPs (311 + 216 + 243 us
+// for forward / dX / dW per step, profiles/r01_h).  The useful work is tiny (K = 64) and HBM-bound: read a
+// [N, T*64] once, write [N, sum C] once.  Kernels (fp32-input MFMA 32x32x2, one wave = one 32-row x one group item):
+//   k_gproj_fwd  A operand = 32 rows x K/2 contiguous floats per lane (16-byte loads, the two lane halves take the two
+//                halves of the K range), B operand = 32 weight rows likewise; K/2 MFMAs per 32-class tile.
+//   k_gproj_dx   da[n, g*K + k] = sum_c dout[n, off_g + c] w[off_g + c, k]; the class range is split between the lane halves.
+//   k_gproj_dw   dw[off_g + c, k] = sum_n dout[n, off_g + c] a[n, g*K + k] and db: both operands "n-major", row pairs
+//                per MFMA step, N cut into S slices -> slabs -> agnn::launch_slab_reduce (fixed order, no atomics).
+// Lanes past a group's class count read the group's last class (valid memory) and their results are never stored.
+#include "agnn_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GpArgs {
+  const float* a;          // [n, G*K]
+  const float* w;          // [sumC, K]
+  const float* b;          // [sumC] or null
+  const float* dout;       // [n, sumC] (ld_out)
+  const int32_t* seg_off;  // device [G+1]
+  float* out;              // fwd: [n, sumC]
+  float* da;               // dx: [n, G*K]
+  float* slab;             // dw: [S][sumC][K]
+  float* slab_b;           // dw: [S][sumC]
+  int64_t ld_a, ld_out, ld_da, n_rows;
+  int32_t G, n_row_tiles, n_tiles32, S, rows_per_slice, sum_c;
+};
+
+__device__ __forceinline__ int d_row(int r, int kk) { return (r & 3) + 8 * (r >> 2) + 4 * kk; }   // C/D layout of 32x32 MFMA
+
+template <int K>
+__global__ __launch_bounds__(256) void k_gproj_fwd(GpArgs p) {
+  constexpr int KH = K / 2;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t item = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+  const int rt = static_cast<int>(item / p.G), g = static_cast<int>(item - static_cast<int64_t>(rt) * p.G);
+  if (rt >= p.n_row_tiles) return;
+  const int j = lane & 31, kk = lane >> 5;
+  const int off = p.seg_off[g], C = p.seg_off[g + 1] - off;
+  if (C <= 0) return;
+  int64_t row = static_cast<int64_t>(rt) * 32 + j;
+  if (row > p.n_rows - 1) row = p.n_rows - 1;
+  float av[KH];
+  const float4* ap = reinterpret_cast<const float4*>(p.a + row * p.ld_a + g * K + kk * KH);
+#pragma unroll
+  for (int q = 0; q < KH / 4; ++q) {
+    const float4 v = ap[q];
+    av[4 * q] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
+  }
+  for (int ct = 0; ct * 32 < C; ++ct) {
+    const int col = ct * 32 + j;
+    const int c = col < C ? col : C - 1;
+    const float4* wp = reinterpret_cast<const float4*>(p.w + static_cast<int64_t>(off + c) * K + kk * KH);
+    float bv[KH];
+#pragma unroll
+    for (int q = 0; q < KH / 4; ++q) {
+      const float4 v = wp[q];
+      bv[4 * q] = v.x; bv[4 * q + 1] = v.y; bv[4 * q + 2] = v.z; bv[4 * q + 3] = v.w;
+    }
+    f32x16 acc = {0};
+#pragma unroll
+    for (int s = 0; s < KH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+    if (col < C) {
+      const float bias = p.b != nullptr ? p.b[off + col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t ro = static_cast<int64_t>(rt) * 32 + d_row(r, kk);
+        if (ro < p.n_rows) p.out[ro * p.ld_out + off + col] = acc[r] + bias;
+      }
+    }
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_gproj_dx(GpArgs p) {
+  constexpr int NT = K / 32;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t item = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+  const int rt = static_cast<int>(item / p.G), g = static_cast<int>(item - static_cast<int64_t>(rt) * p.G);
+  if (rt >= p.n_row_tiles) return;
+  const int j = lane & 31, kk = lane >> 5;
+  const int off = p.seg_off[g], C = p.seg_off[g + 1] - off;
+  const int Ch = (C + 1) >> 1;                      // classes [0, Ch) on lane half 0, [Ch, C) on lane half 1
+  int64_t row = static_cast<int64_t>(rt) * 32 + j;
+  if (row > p.n_rows - 1) row = p.n_rows - 1;
+  const float* dp = p.dout + row * p.ld_out + off;
+  const float* wp = p.w + static_cast<int64_t>(off) * K + j;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
+  for (int s0 = 0; s0 < Ch; s0 += 8) {
+    float avv[8], bvv[8][NT];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int s = s0 + u, c = kk * Ch + s;
+      const float m = (s < Ch && c < C) ? 1.f : 0.f;
+      const int cc = c < C ? c : C - 1;
+      avv[u] = dp[cc] * m;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bvv[u][t] = wp[static_cast<int64_t>(cc) * K + t * 32];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(avv[u], bvv[u][t], acc[t], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t ro = static_cast<int64_t>(rt) * 32 + d_row(r, kk);
+      if (ro < p.n_rows) p.da[ro * p.ld_da + g * K + t * 32 + j] = acc[t][r];
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_gproj_dw(GpArgs p) {
+  constexpr int NT = K / 32;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t id = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+  const int slice = static_cast<int>(id / p.n_tiles32), tile = static_cast<int>(id - static_cast<int64_t>(slice) * p.n_tiles32);
+  if (slice >= p.S) return;
+  int g = -1, ct = 0, off = 0, C = 0;
+  for (int q = 0, base = 0; q < p.G; ++q) {          // wave-uniform scan of the (<= 32) groups
+    const int o = p.seg_off[q], cq = p.seg_off[q + 1] - o, nt = (cq + 31) >> 5;
+    if (tile < base + nt) { g = q; ct = tile - base; off = o; C = cq; break; }
+    base += nt;
+  }
+  if (g < 0) return;
+  const int j = lane & 31, kk = lane >> 5;
+  const int r0 = slice * p.rows_per_slice;
+  int r1 = r0 + p.rows_per_slice;
+  if (r1 > p.n_rows) r1 = static_cast<int>(p.n_rows);
+  const int col = ct * 32 + j;
+  const int c = col < C ? col : C - 1;
+  const float* dp = p.dout + off + c;
+  const float* ap = p.a + g * K + j;
+  const int n_last = static_cast<int>(p.n_rows) - 1;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
+  float bs = 0.f;
+  for (int base = r0; base < r1; base += 16) {
+    float avv[8], bvv[8][NT];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int n = base + 2 * u + kk;
+      const float m = n < r1 ? 1.f : 0.f;
+      const int64_t nn = n < n_last ? n : n_last;
+      avv[u] = dp[nn * p.ld_out] * m;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bvv[u][t] = ap[nn * p.ld_a + t * 32];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(avv[u], bvv[u][t], acc[t], 0, 0, 0);
+      bs += avv[u];
+    }
+  }
+  float* slab = p.slab + (static_cast<int64_t>(slice) * p.sum_c + off) * K;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = ct * 32 + d_row(r, kk);          // D row = class index (A operand), D column = k
+      if (ci < C) slab[static_cast<int64_t>(ci) * K + t * 32 + j] = acc[t][r];
+    }
+  if (p.slab_b != nullptr) {
+    bs += __shfl_xor(bs, 32, 64);                     // the two lane halves hold the two row parities
+    if (kk == 0 && col < C) p.slab_b[static_cast<int64_t>(slice) * p.sum_c + off + col] = bs;
+  }
+}
+
+struct Plan { int S, rows_per_slice; };
+
+Plan make_plan(int64_t n, int n_tiles32) {
+  int64_t S = (2048 + n_tiles32 - 1) / n_tiles32;   // ~2 waves per SIMD over the whole chip
+  const int64_t max_s = (n + 63) / 64;
+  if (S > max_s) S = max_s;
+  if (S > 64) S = 64;
+  if (S < 1) S = 1;
+  int64_t rps = (n + S - 1) / S;
+  rps = (rps + 1) & ~int64_t{1};
+  Plan p;
+  p.rows_per_slice = static_cast<int>(rps);
+  p.S = static_cast<int>((n + rps - 1) / rps);
+  return p;
+}
+
+int check_common(const char* what, const void* a, int64_t ld_a, const void* w, const int32_t* seg_off, int32_t G, int32_t K,
+                 int32_t n_tiles32, int64_t n_rows) {
+  using namespace agnn;
+  if (n_rows < 0 || n_rows >= (int64_t{1} << 31) || G <= 0 || G > AGNN_MAX_SEG || n_tiles32 < 0)
+    return fail(AGNN_EINVAL, "%s: bad sizes n=%lld groups=%d tiles=%d", what, (long long)n_rows, G, n_tiles32);
+  if (K != 32 && K != 64 && K != 128) return fail(AGNN_EINVAL, "%s: K=%d (32, 64 or 128)", what, K);
+  if (!a || !w || !seg_off) return fail(AGNN_EINVAL, "%s: null argument", what);
+  if (!aligned16(a) || !aligned16(w) || (ld_a & 3)) return fail(AGNN_EALIGN, "%s: a / w must be 16-byte aligned, ld_a %% 4 == 0", what);
+  if (ld_a < static_cast<int64_t>(G) * K) return fail(AGNN_EINVAL, "%s: ld_a smaller than groups*K", what);
+  return AGNN_OK;
+}
+
+}  // namespace
+
+extern "C" int agnn_gproj_fwd_f32(const float* a, int64_t ld_a, const float* w, const float* b, const int32_t* seg_off,
+                                  int32_t n_groups, int32_t K, int32_t n_tiles32, int64_t n_rows, float* out, int64_t ld_out,
+                                  agnn_stream_t stream_) {
+  using namespace agnn;
+  if (int rc = check_common("gproj_fwd", a, ld_a, w, seg_off, n_groups, K, n_tiles32, n_rows)) return rc;
+  if (!out) return fail(AGNN_EINVAL, "gproj_fwd: null output");
+  if (n_rows == 0 || n_tiles32 == 0) return AGNN_OK;
+  GpArgs p{};
+  p.a = a; p.w = w; p.b = b; p.seg_off = seg_off; p.out = out;
+  p.ld_a = ld_a; p.ld_out = ld_out; p.n_rows = n_rows; p.G = n_groups;
+  p.n_row_tiles = static_cast<int32_t>((n_rows + 31) / 32);
+  const int64_t items = static_cast<int64_t>(p.n_row_tiles) * n_groups;
+  const dim3 grid(static_cast<unsigned>((items + 3) / 4));
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  if (K == 32) hipLaunchKernelGGL(k_gproj_fwd<32>, grid, dim3(256), 0, s, p);
+  else if (K == 64) hipLaunchKernelGGL(k_gproj_fwd<64>, grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(k_gproj_fwd<128>, grid, dim3(256), 0, s, p);
+  return check_launch("gproj_fwd");
+}
+
+extern "C" size_t agnn_gproj_workspace_bytes(int64_t n_rows, int32_t sum_c, int32_t K, int32_t n_tiles32) {
+  if (n_rows <= 0 || sum_c <= 0 || K <= 0 || n_tiles32 <= 0) return 0;
+  const Plan pl = make_plan(n_rows, n_tiles32);
+  return static_cast<size_t>(pl.S) * sum_c * (static_cast<size_t>(K) + 1) * sizeof(float) + 256;
+}
+
+extern "C" int agnn_gproj_bwd_f32(const float* dout, int64_t ld_dout, const float* a, int64_t ld_a, const float* w,
+                                  const int32_t* seg_off, int32_t n_groups, int32_t K, int32_t n_tiles32, int32_t sum_c,
+                                  int64_t n_rows, float* da, int64_t ld_da, float* dw, float* db, void* workspace,
+                                  size_t workspace_bytes, agnn_stream_t stream_) {
+  using namespace agnn;
+  if (int rc = check_common("gproj_bwd", a, ld_a, w, seg_off, n_groups, K, n_tiles32, n_rows)) return rc;
+  if (!dout || sum_c < 0 || ld_dout < sum_c) return fail(AGNN_EINVAL, "gproj_bwd: bad dout / sum_c");
+  if (n_rows == 0 || n_tiles32 == 0 || sum_c == 0) return AGNN_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  GpArgs p{};
+  p.a = a; p.w = w; p.dout = dout; p.seg_off = seg_off;
+  p.ld_a = ld_a; p.ld_out = ld_dout; p.n_rows = n_rows; p.G = n_groups; p.sum_c = sum_c; p.n_tiles32 = n_tiles32;
+  p.n_row_tiles = static_cast<int32_t>((n_rows + 31) / 32);
+  if (da != nullptr) {
+    if (ld_da < static_cast<int64_t>(n_groups) * K) return fail(AGNN_EINVAL, "gproj_bwd: ld_da smaller than groups*K");
+    p.da = da; p.ld_da = ld_da;
+    const int64_t items = static_cast<int64_t>(p.n_row_tiles) * n_groups;
+    const dim3 grid(static_cast<unsigned>((items + 3) / 4));
+    if (K == 32) hipLaunchKernelGGL(k_gproj_dx<32>, grid, dim3(256), 0, s, p);
+    else if (K == 64) hipLaunchKernelGGL(k_gproj_dx<64>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_gproj_dx<128>, grid, dim3(256), 0, s, p);
+    if (int rc = check_launch("gproj_dx")) return rc;
+  }
+  if (dw != nullptr) {
+    const size_t need = agnn_gproj_workspace_bytes(n_rows, sum_c, K, n_tiles32);
+    if (!workspace || workspace_bytes < need) return fail(AGNN_ENOMEM, "gproj_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    const Plan pl = make_plan(n_rows, n_tiles32);
+    char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t{255});
+    p.slab = reinterpret_cast<float*>(ws);
+    p.slab_b = db != nullptr ? p.slab + static_cast<size_t>(pl.S) * sum_c * K : nullptr;
+    p.S = pl.S;
+    p.rows_per_slice = pl.rows_per_slice;
+    const int64_t waves = static_cast<int64_t>(pl.S) * n_tiles32;
+    const dim3 grid(static_cast<unsigned>((waves + 3) / 4));
+    if (K == 32) hipLaunchKernelGGL(k_gproj_dw<32>, grid, dim3(256), 0, s, p);
+    else if (K == 64) hipLaunchKernelGGL(k_gproj_dw<64>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_gproj_dw<128>, grid, dim3(256), 0, s, p);
+    if (int rc = check_launch("gproj_dw")) return rc;
+    return launch_slab_reduce(p.slab, p.slab_b, pl.S, sum_c, K, sum_c, K, dw, K, db, s);
+  }
+  return AGNN_OK;
+}

@@ -16,53 +16,83 @@
 
 namespace {
 
-__device__ __forceinline__ float wave_max(float v) {
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+using agnn::lane_value;
+using agnn::wave_max_dpp;
+using agnn::wave_sum_dpp;
 
+// One wavefront per row.  A task's logits sit in up to three registers per lane (C <= 192 covers every head of the
+// reference; wider segments take the strided loops below); the next task's values and label are fetched while the
+// current task is reduced (DPP reductions, v_exp / v_log), so the 21 tasks of a row do not pay 21 load latencies.
 __global__ __launch_bounds__(256) void k_mtce(const float* __restrict__ z, int64_t ld, const int32_t* __restrict__ off, int T,
                                               const int64_t* __restrict__ labels, int64_t n_rows, float eps, int64_t ignore,
                                               const float* __restrict__ inv_cnt, float* __restrict__ row_loss,
                                               float* __restrict__ dz) {
   const int lane = threadIdx.x & 63;
-  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (row >= n_rows) return;
   const float* zr = z + row * ld;
   float* dr = dz + row * ld;
+  float n0, n1, n2;
+  int64_t ny;
+  auto fetch = [&](int t) {
+    const int a = off[t], b = off[t + 1];
+    n0 = (a + lane < b) ? zr[a + lane] : -INFINITY;
+    n1 = (a + 64 + lane < b) ? zr[a + 64 + lane] : -INFINITY;
+    n2 = (a + 128 + lane < b) ? zr[a + 128 + lane] : -INFINITY;
+    ny = labels[static_cast<int64_t>(t) * n_rows + row];
+  };
+  fetch(0);
   for (int t = 0; t < T; ++t) {
     const int a = off[t], b = off[t + 1];
     const int C = b - a;
-    const int64_t y = labels[static_cast<int64_t>(t) * n_rows + row];
+    const float v0 = n0, v1 = n1, v2 = n2;
+    const int64_t y = ny;
+    if (t + 1 < T) fetch(t + 1);
     const bool valid = (y != ignore);
-    float mx = -INFINITY;
-    for (int c = a + lane; c < b; c += 64) mx = fmaxf(mx, zr[c]);
-    mx = wave_max(mx);
-    float se = 0.f, sz = 0.f;
-    for (int c = a + lane; c < b; c += 64) {
-      const float v = zr[c];
-      se += expf(v - mx);
-      sz += v;
-    }
-    se = wave_sum(se);
-    sz = wave_sum(sz);
-    const float lse = mx + logf(se);
-    float loss = 0.f;
-    if (valid) {
-      const float zy = zr[a + static_cast<int>(y)];
-      loss = (1.f - eps) * (lse - zy) + eps * (lse - sz / static_cast<float>(C));
-    }
-    if (lane == 0) row_loss[row * T + t] = loss;
     const float sc = valid ? inv_cnt[t] : 0.f;
     const float sm = eps / static_cast<float>(C);
-    for (int c = a + lane; c < b; c += 64) {
-      const float p = expf(zr[c] - lse);
-      const float tgt = ((c - a) == y ? (1.f - eps) : 0.f) + sm;
-      dr[c] = sc * (p - tgt);
+    if (C <= 192) {
+      const float mx = wave_max_dpp(fmaxf(fmaxf(v0, v1), v2));
+      const float e0 = __expf(v0 - mx), e1 = __expf(v1 - mx), e2 = __expf(v2 - mx);        // exp(-inf) = 0 for absent classes
+      const float se = wave_sum_dpp((e0 + e1) + e2);
+      const float sz = wave_sum_dpp(((a + lane < b ? v0 : 0.f) + (a + 64 + lane < b ? v1 : 0.f)) + (a + 128 + lane < b ? v2 : 0.f));
+      const float lse = mx + __logf(se);
+      float loss = 0.f;
+      if (valid) {
+        const int yi = static_cast<int>(y);
+        const float zy = lane_value(yi < 64 ? v0 : (yi < 128 ? v1 : v2), yi & 63);
+        loss = (1.f - eps) * (lse - zy) + eps * (lse - sz / static_cast<float>(C));
+      }
+      if (lane == 0) row_loss[row * T + t] = loss;
+      const float inv = 1.f / se;
+      const int yl = static_cast<int>(y) - lane;                      // class c = lane + 64 k is the label when yl == 64 k
+      if (a + lane < b) dr[a + lane] = sc * (e0 * inv - ((yl == 0 ? 1.f - eps : 0.f) + sm));
+      if (a + 64 + lane < b) dr[a + 64 + lane] = sc * (e1 * inv - ((yl == 64 ? 1.f - eps : 0.f) + sm));
+      if (a + 128 + lane < b) dr[a + 128 + lane] = sc * (e2 * inv - ((yl == 128 ? 1.f - eps : 0.f) + sm));
+    } else {
+      float mx = -INFINITY;
+      for (int c = a + lane; c < b; c += 64) mx = fmaxf(mx, zr[c]);
+      mx = wave_max_dpp(mx);
+      float se = 0.f, sz = 0.f;
+      for (int c = a + lane; c < b; c += 64) {
+        const float v = zr[c];
+        se += __expf(v - mx);
+        sz += v;
+      }
+      se = wave_sum_dpp(se);
+      sz = wave_sum_dpp(sz);
+      const float lse = mx + __logf(se);
+      float loss = 0.f;
+      if (valid) {
+        const float zy = zr[a + static_cast<int>(y)];
+        loss = (1.f - eps) * (lse - zy) + eps * (lse - sz / static_cast<float>(C));
+      }
+      if (lane == 0) row_loss[row * T + t] = loss;
+      for (int c = a + lane; c < b; c += 64) {
+        const float p = __expf(zr[c] - lse);
+        const float tgt = ((c - a) == y ? (1.f - eps) : 0.f) + sm;
+        dr[c] = sc * (p - tgt);
+      }
     }
   }
 }

@@ -55,13 +55,14 @@ __device__ __forceinline__ float4 keep_mask(const NaArgs& a, int64_t row, int ch
   return make_float4(r.x >= thr ? scale : 0.f, r.y >= thr ? scale : 0.f, r.z >= thr ? scale : 0.f, r.w >= thr ? scale : 0.f);
 }
 
-__device__ __forceinline__ float wsum(float v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-// sum over the gl (power of two <= 64) adjacent lanes that hold one segment
+__device__ __forceinline__ float wsum(float v) { return agnn::wave_sum_dpp(v); }
+// sum over the gl (power of two <= 64) adjacent lanes that hold one segment (DPP inside a 16-lane row)
 __device__ __forceinline__ float gsum(float v, int gl) {
-  for (int o = 1; o < gl; o <<= 1) v += __shfl_xor(v, o, 64);
+  if (gl >= 2) v += agnn::dpp_mov<0xB1>(v);
+  if (gl >= 4) v += agnn::dpp_mov<0x4E>(v);
+  if (gl >= 8) v += agnn::dpp_mov<0x141>(v);
+  if (gl >= 16) v += agnn::dpp_mov<0x140>(v);
+  for (int o = 16; o < gl; o <<= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
 
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256) void k_na_fwd(NaArgs a, float* __restrict__ y,
   }
 }
 
-// grid-stride over rows; per-wave partial dgamma / dbeta rows -> part[wave_global][2][H]
+// grid-stride over rows; per-block partial dgamma / dbeta rows -> part[block][2][H]
 template <int CH>
 __global__ __launch_bounds__(256) void k_na_bwd(NaArgs a, const float* __restrict__ dy, int64_t ld_dy, const float* __restrict__ mean_in,
                                                 const float* __restrict__ rstd_in, float* __restrict__ dx, int64_t ld_dx,
@@ -216,36 +217,59 @@ __global__ __launch_bounds__(256) void k_na_bwd(NaArgs a, const float* __restric
       op[c * 64 + lane] = o;
     }
   }
-  float4* pg = reinterpret_cast<float4*>(part + static_cast<int64_t>(wave_g) * 2 * a.H);
-  float4* pb = reinterpret_cast<float4*>(part + static_cast<int64_t>(wave_g) * 2 * a.H + a.H);
+  // the block's four waves add their partial rows in LDS in a fixed order, then one row per BLOCK goes to `part`
+  __shared__ float4 sm[2 * 64 * CH];
+  const int wave = threadIdx.x >> 6;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    if (!on[c]) continue;
-    pg[c * 64 + lane] = dg[c];
-    pb[c * 64 + lane] = db[c];
+      for (int c = 0; c < CH; ++c) {
+        float4 g = dg[c], b = db[c];
+        if (w > 0) {
+          const float4 pg = sm[c * 64 + lane], pb = sm[(CH + c) * 64 + lane];
+          g.x += pg.x; g.y += pg.y; g.z += pg.z; g.w += pg.w;
+          b.x += pb.x; b.y += pb.y; b.z += pb.z; b.w += pb.w;
+        }
+        sm[c * 64 + lane] = g;
+        sm[(CH + c) * 64 + lane] = b;
+      }
+    }
+    __syncthreads();
+  }
+  if (wave == 0) {
+    float4* pg = reinterpret_cast<float4*>(part + static_cast<int64_t>(blockIdx.x) * 2 * a.H);
+    float4* pb = reinterpret_cast<float4*>(part + static_cast<int64_t>(blockIdx.x) * 2 * a.H + a.H);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (!on[c]) continue;
+      pg[c * 64 + lane] = sm[c * 64 + lane];
+      pb[c * 64 + lane] = sm[(CH + c) * 64 + lane];
+    }
   }
 }
 
-// dgamma[j] | dbeta[j] = sum over waves of part[w][j | H + j].  Block = 32 columns x 8 partial sums (fixed order).
-__global__ __launch_bounds__(256) void k_na_colsum(const float* __restrict__ part, int n_waves, int width, float* __restrict__ dgamma,
-                                                   float* __restrict__ dbeta, int H) {
-  __shared__ float sm[8][32];
+// dgamma[j] | dbeta[j] = sum over blocks of part[b][j | H + j].  Block = 32 columns x 32 partial sums (fixed order).
+__global__ __launch_bounds__(1024) void k_na_colsum(const float* __restrict__ part, int n_rows, int width, float* __restrict__ dgamma,
+                                                    float* __restrict__ dbeta, int H) {
+  __shared__ float sm[32][33];
   const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int j = blockIdx.x * 32 + col;
   float s = 0.f;
-  if (j < width)
-    for (int w = grp; w < n_waves; w += 8) s += part[static_cast<int64_t>(w) * width + j];
+  if (j < width) {
+#pragma unroll 8
+    for (int w = grp; w < n_rows; w += 32) s += part[static_cast<int64_t>(w) * width + j];
+  }
   sm[grp][col] = s;
   __syncthreads();
   if (grp == 0 && j < width) {
     float t = sm[0][col];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) t += sm[k][col];
+    for (int k = 1; k < 32; ++k) t += sm[k][col];
     if (j < H) dgamma[j] = t; else dbeta[j - H] = t;
   }
 }
 
-constexpr int kBwdBlocks = 256;     // 1024 waves: partial slab = 1024 * 2H floats
+constexpr int kBwdBlocks = 1024;    // 4 waves per SIMD; partial slab = 1024 * 2H floats (one row per block)
 
 int na_check(const char* who, const void* x, int64_t ld_x, const void* gamma, const void* beta, int64_t n, int32_t H, int32_t seg,
              float p, const void* rng) {
@@ -266,7 +290,7 @@ int na_check(const char* who, const void* x, int64_t ld_x, const void* gamma, co
 
 }  // namespace
 
-extern "C" size_t agnn_norm_act_workspace_bytes(int32_t H) { return static_cast<size_t>(kBwdBlocks) * 4 * 2 * static_cast<size_t>(H > 0 ? H : 0) * sizeof(float); }
+extern "C" size_t agnn_norm_act_workspace_bytes(int32_t H) { return static_cast<size_t>(kBwdBlocks) * 2 * static_cast<size_t>(H > 0 ? H : 0) * sizeof(float); }
 
 #define AGNN_NA_DISPATCH(KERN, ...)                                                          \
   do {                                                                                       \
@@ -304,10 +328,12 @@ extern "C" int agnn_norm_act_bwd_f32(const float* x, int64_t ld_x, const float* 
   NaArgs a{x, ld_x, gamma, beta, n, H, eps, p, flags, rng_state, call_id, seg};
   float* part = static_cast<float*>(workspace);
   hipStream_t s = static_cast<hipStream_t>(stream_);
-  const dim3 grid(kBwdBlocks), block(256);
+  int nb = static_cast<int>((n + 3) / 4);                 // at least one row per wave
+  if (nb > kBwdBlocks) nb = kBwdBlocks;
+  const dim3 grid(nb), block(256);
   AGNN_NA_DISPATCH(k_na_bwd, a, dy, ld_dy, mean, rstd, dx, ld_dx, part);
   if (int rc = check_launch("norm_act_bwd")) return rc;
   const int width = 2 * H;
-  hipLaunchKernelGGL(k_na_colsum, dim3((width + 31) / 32), dim3(256), 0, s, part, kBwdBlocks * 4, width, dgamma, dbeta, H);
+  hipLaunchKernelGGL(k_na_colsum, dim3((width + 31) / 32), dim3(1024), 0, s, part, nb, width, dgamma, dbeta, H);
   return check_launch("norm_act_colsum");
 }

@@ -172,23 +172,19 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
   }
   if (db != nullptr) {
     // same 32 x 8 decomposition for the bias slabs (a serial walk over S slabs cost ~19 us of load latency)
-    const int half_out = out_f >> 1;
-    for (int e0 = blockIdx.x * 32; e0 < half_out; e0 += gridDim.x * 32) {
+    __shared__ float partb[8][32];
+    for (int e0 = blockIdx.x * 32; e0 < out_f; e0 += gridDim.x * 32) {
       const int e = e0 + col;
-      float2 s = make_float2(0.f, 0.f);
-      if (e < half_out)
-        for (int k = sg; k < S; k += 8) {
-          const float2 v = *reinterpret_cast<const float2*>(slab_b + static_cast<int64_t>(k) * out_pad + 2 * e);
-          s.x += v.x;
-          s.y += v.y;
-        }
-      part[sg][col] = s;
+      float s = 0.f;
+      if (e < out_f)
+        for (int k = sg; k < S; k += 8) s += slab_b[static_cast<int64_t>(k) * out_pad + e];
+      partb[sg][col] = s;
       __syncthreads();
-      if (sg == 0 && e < half_out) {
-        float2 t = part[0][col];
+      if (sg == 0 && e < out_f) {
+        float t = partb[0][col];
 #pragma unroll
-        for (int g = 1; g < 8; ++g) { t.x += part[g][col].x; t.y += part[g][col].y; }
-        *reinterpret_cast<float2*>(db + 2 * e) = t;
+        for (int g = 1; g < 8; ++g) t += partb[g][col];
+        db[e] = t;
       }
       __syncthreads();
     }
@@ -220,6 +216,17 @@ Plan make_plan(int64_t n, int out_f, int in_f) {
 
 }  // namespace
 
+// dw[o][i] = sum_s slab[s][o][i] (in_f even), db[o] = sum_s slab_b[s][o]; shared with gproj.hip
+int agnn::launch_slab_reduce(const float* slab, const float* slab_b, int S, int out_f, int in_f, int out_pad, int in_pad,
+                             float* dw, int64_t ld_dw, float* db, hipStream_t s) {
+  const int64_t total = static_cast<int64_t>(out_f) * (in_f >> 1);
+  int blocks = static_cast<int>((total + 31) / 32);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks), dim3(256), 0, s, slab, slab_b, S, out_f, in_f, out_pad, in_pad, dw, ld_dw, db);
+  return check_launch("slab_reduce");
+}
+
 extern "C" size_t agnn_wgrad_workspace_bytes(int64_t n, int32_t out_f, int32_t in_f) {
   if (n <= 0 || out_f <= 0 || in_f <= 0) return 0;
   const Plan p = make_plan(n, out_f, in_f);
@@ -249,10 +256,5 @@ extern "C" int agnn_wgrad_f32(const float* dy, int64_t ld_dy, const float* x, in
   hipStream_t s = static_cast<hipStream_t>(stream_);
   hipLaunchKernelGGL(k_wgrad, dim3(p.tiles_out * p.tiles_in, p.S), dim3(256), 0, s, a);
   if (int rc = check_launch("wgrad")) return rc;
-  const int64_t total = static_cast<int64_t>(out_f) * (in_f >> 1);
-  int blocks = static_cast<int>((total + 31) / 32);
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks), dim3(256), 0, s, slab, db ? slab_b : nullptr, p.S, out_f, in_f, p.out_pad,
-                     p.in_pad, dw, ld_dw, db);
-  return check_launch("wgrad_reduce");
+  return launch_slab_reduce(slab, db ? slab_b : nullptr, p.S, out_f, in_f, p.out_pad, p.in_pad, dw, ld_dw, db, s);
 }

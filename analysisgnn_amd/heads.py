@@ -7,7 +7,8 @@ weight-gradient GEMMs are 64 x 128 outputs with K = N (4 workgroups on a 256-CU 
 (`clf_dict.<task>.{0,2,3}` stay ordinary modules, `state_dict` unchanged), different schedule:
   * first layers stacked into ONE GEMM  [N, o] x [o, T*h2]
   * ReLU + LayerNorm over each task's h2-wide group in one pass on the [N, T, h2] view
-  * second layers as ONE GEMM against the block-diagonal [sum C, T*h2] weight -> logits side by side [N, sum C]
+  * second layers as ONE grouped projection (`agnn_gproj_*`: task t reads its own h2 columns and writes its own C_t
+    logit columns side by side [N, sum C]; a block-diagonal library GEMM did 21x the useful FLOPs)
   * one C-ABI kernel for all T cross-entropy terms and their gradient (`agnn_multitask_ce_f32`).
 """
 from __future__ import annotations
@@ -34,13 +35,76 @@ def fused_head_logits(clf_dict: nn.ModuleDict, x: torch.Tensor, tasks: Sequence[
     gamma = torch.stack([m[2].weight for m in mods])                      # [T, h2]
     beta = torch.stack([m[2].bias for m in mods])
     a = grouped_norm_act(a.view(-1, T, h2), gamma, beta, mods[0][2].eps, pre_relu=True)   # ReLU + per-task LayerNorm, one launch
-    W2 = torch.block_diag(*[m[3].weight for m in mods])                   # [sum C, T*h2]
-    b2 = torch.cat([m[3].bias for m in mods], dim=0)
-    logits = linear(a.reshape(-1, T * h2), W2, b2)
     offs = [0]
     for m in mods:
         offs.append(offs[-1] + m[3].out_features)
+    b2 = torch.cat([m[3].bias for m in mods], dim=0)
+    a = a.reshape(-1, T * h2)
+    if a.is_cuda and h2 in GPROJ_K and T <= _lib.MAX_SEG and GPROJ_ENABLED:
+        W2 = torch.cat([m[3].weight for m in mods], dim=0)                # [sum C, h2]
+        logits = grouped_projection(a, W2, b2, offs, h2)
+    else:                                                                 # widths the kernel is not built for
+        W2 = torch.block_diag(*[m[3].weight for m in mods])               # [sum C, T*h2]
+        logits = linear(a, W2, b2)
     return logits, offs
+
+
+GPROJ_K = (32, 64, 128)
+GPROJ_ENABLED = True     # A/B switch for benchmarking
+
+
+def _offs_tensor(offs: Sequence[int], device) -> torch.Tensor:
+    key = (tuple(offs), str(device))
+    t = _OFFS_CACHE.get(key)
+    if t is None:                            # host -> device once per head layout (keeps the step graph-capturable)
+        t = _OFFS_CACHE[key] = torch.tensor(list(offs), dtype=torch.int32, device=device)
+    return t
+
+
+class _GroupedProj(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, w, b, offs_t, offs, K):
+        dev = _lib.require_gpu(a, w, offs_t)
+        a = _lib.f32c(a)
+        w = _lib.f32c(w)
+        if w.data_ptr() % 16:
+            w = w.clone()
+        G = len(offs) - 1
+        sum_c = offs[-1]
+        tiles = sum((offs[i + 1] - offs[i] + 31) // 32 for i in range(G))
+        N = a.shape[0]
+        out = torch.empty((N, sum_c), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        bb = b.float().contiguous() if b is not None else None
+        _lib.check(lib.agnn_gproj_fwd_f32(a.data_ptr(), a.stride(0), w.data_ptr(), _lib.ptr(bb), offs_t.data_ptr(), G, K, tiles, N,
+                                          out.data_ptr(), out.stride(0), _lib.stream_ptr(dev)), "agnn_gproj_fwd_f32")
+        ctx.save_for_backward(a, w, offs_t)
+        ctx.meta = (G, K, tiles, sum_c, b is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, w, offs_t = ctx.saved_tensors
+        G, K, tiles, sum_c, has_b = ctx.meta
+        dev = a.device
+        dout = _lib.f32c(dout)
+        N = a.shape[0]
+        lib = _lib.load()
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        need_w = ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2])
+        dw = torch.empty_like(w) if need_w else None
+        db = torch.empty((sum_c,), dtype=torch.float32, device=dev) if (need_w and has_b) else None
+        nws = int(lib.agnn_gproj_workspace_bytes(N, sum_c, K, tiles)) if need_w else 0
+        ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=dev)
+        _lib.check(lib.agnn_gproj_bwd_f32(dout.data_ptr(), dout.stride(0), a.data_ptr(), a.stride(0), w.data_ptr(), offs_t.data_ptr(),
+                                          G, K, tiles, sum_c, N, _lib.ptr(da), da.stride(0) if da is not None else 0, _lib.ptr(dw),
+                                          _lib.ptr(db), ws.data_ptr(), nws, _lib.stream_ptr(dev)), "agnn_gproj_bwd_f32")
+        return da, dw, db, None, None, None
+
+
+def grouped_projection(a: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], offs: Sequence[int], K: int) -> torch.Tensor:
+    """out[:, offs[g]:offs[g+1]] = a[:, g*K:(g+1)*K] @ w[offs[g]:offs[g+1]].T + b[offs[g]:offs[g+1]]  for every group g."""
+    return _GroupedProj.apply(a, w, b, _offs_tensor(offs, a.device), tuple(int(o) for o in offs), int(K))
 
 
 class _MultiTaskCE(torch.autograd.Function):
@@ -75,11 +139,7 @@ class _MultiTaskCE(torch.autograd.Function):
 def multitask_cross_entropy(logits: torch.Tensor, offs: Sequence[int], labels: torch.Tensor, label_smoothing: float = 0.1,
                             ignore_index: int = -1) -> torch.Tensor:
     """Per-task mean losses [T] for side-by-side logits [N, sum C]; labels int64 [T, N]."""
-    key = (tuple(offs), str(logits.device))
-    offs_t = _OFFS_CACHE.get(key)
-    if offs_t is None:                       # host -> device once per head layout (keeps the step graph-capturable)
-        offs_t = _OFFS_CACHE[key] = torch.tensor(list(offs), dtype=torch.int32, device=logits.device)
-    return _MultiTaskCE.apply(logits, labels, offs_t, label_smoothing, ignore_index)
+    return _MultiTaskCE.apply(logits, labels, _offs_tensor(offs, logits.device), label_smoothing, ignore_index)
 
 
 _OFFS_CACHE: Dict[tuple, torch.Tensor] = {}

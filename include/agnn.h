@@ -18,6 +18,7 @@
  *   agnn_gated_*          `ResGatedGraphConv` edge gate + scatter (ref: core/gnn.py:246-257)
  *   agnn_norm_act_*       LayerNorm / ReLU / Dropout chains between the projections (ref: models/analysis.py:429-443)
  *   agnn_wgrad_f32        weight/bias gradients of the dense projections (fp32 MFMA, split over N)
+ *   agnn_gproj_*          the task heads' last Linear layers as one grouped projection (ref: models/analysis.py:486-496)
  *   agnn_multitask_ce_f32 the 21 per-task CrossEntropyLoss terms (ref: models/analysis.py:881-888)
  *   agnn_hgt_attn_*       PyG `HGTConv` message/softmax/aggregate, reached through graphmuse
  *                         `HybridHGT` (ref: models/analysis.py:445-453)
@@ -246,6 +247,25 @@ size_t agnn_wgrad_workspace_bytes(int64_t n, int32_t out_f, int32_t in_f);
 int agnn_wgrad_f32(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, int64_t n, int32_t out_f,
                    int32_t in_f, float* dw, int64_t ld_dw, float* db, void* workspace, size_t workspace_bytes,
                    agnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Grouped projection: the last Linear(h2 -> C_t) of all task heads in one launch per direction
+ * (ref: models/analysis.py:486-496 `clf_dict[task]`, :546-548).  Group g reads columns [g*K, (g+1)*K) of a and
+ * owns output columns [seg_off[g], seg_off[g+1]) (the same side-by-side logits layout agnn_multitask_ce_f32 takes):
+ *     out[n, seg_off[g] + c] = b[seg_off[g] + c] + sum_k a[n, g*K + k] * w[seg_off[g] + c, k]
+ *   a [n_rows, n_groups*K] (ld_a), w [sum_c, K] = the per-task weights stacked along rows, b [sum_c] or NULL,
+ *   seg_off DEVICE int32 [n_groups + 1], n_tiles32 = sum_g ceil(C_g / 32) (host-side count that sizes the grid),
+ *   K in {32, 64, 128}.  Backward: da [n_rows, n_groups*K] (NULL to skip), dw [sum_c, K] and db [sum_c] (dw NULL to
+ *   skip both; db may be NULL); dw/db are summed over row slices held in `workspace` in a fixed order.
+ * ------------------------------------------------------------------------------------------ */
+int agnn_gproj_fwd_f32(const float* a, int64_t ld_a, const float* w, const float* b, const int32_t* seg_off,
+                       int32_t n_groups, int32_t K, int32_t n_tiles32, int64_t n_rows, float* out, int64_t ld_out,
+                       agnn_stream_t stream);
+size_t agnn_gproj_workspace_bytes(int64_t n_rows, int32_t sum_c, int32_t K, int32_t n_tiles32);
+int agnn_gproj_bwd_f32(const float* dout, int64_t ld_dout, const float* a, int64_t ld_a, const float* w,
+                       const int32_t* seg_off, int32_t n_groups, int32_t K, int32_t n_tiles32, int32_t sum_c,
+                       int64_t n_rows, float* da, int64_t ld_da, float* dw, float* db, void* workspace,
+                       size_t workspace_bytes, agnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused multi-task cross entropy (label smoothing, ignore index) over column segments of one logits

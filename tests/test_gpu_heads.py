@@ -72,3 +72,29 @@ def test_model_forward_clf_is_dict_of_views():
     assert list(out) == ["a", "b"] and out["a"].shape == (11, 3) and out["b"].shape == (11, 7)
     assert_close(out["b"], m.clf_dict["b"](x), 1e-5)
     assert list(m.forward_clf(x, tasks=["b"])) == ["b"]
+
+
+@pytest.mark.parametrize("K,classes,N", [(64, [2, 185, 33, 32, 1, 64, 7], 1003), (32, [5, 40], 70), (128, [3, 97, 31], 257),
+                                         (64, [12] * 21, 4100)])
+def test_grouped_projection_matches_per_task_linear(K, classes, N):
+    """agnn_gproj_* against T separate nn.Linear(K, C_t) evaluated in float64 (forward, da, dw, db)."""
+    from analysisgnn_amd.heads import grouped_projection
+    torch.manual_seed(0)
+    G = len(classes)
+    offs = [0]
+    for c in classes:
+        offs.append(offs[-1] + c)
+    a = torch.randn(N, G * K)
+    w = torch.randn(offs[-1], K) * 0.2
+    b = torch.randn(offs[-1])
+    gout = torch.randn(N, offs[-1])
+    a64, w64, b64 = (t.double().requires_grad_(True) for t in (a, w, b))
+    ref = torch.cat([a64[:, g * K:(g + 1) * K] @ w64[offs[g]:offs[g + 1]].t() + b64[offs[g]:offs[g + 1]] for g in range(G)], dim=1)
+    ref.backward(gout.double())
+    ag, wg, bg = (t.to(DEV).requires_grad_(True) for t in (a, w, b))
+    out = grouped_projection(ag, wg, bg, offs, K)
+    out.backward(gout.to(DEV))
+    assert_close(out, ref.float(), 1e-5, "out")
+    assert_close(ag.grad, a64.grad.float(), 1e-5, "da")
+    assert_close(wg.grad, w64.grad.float(), 1e-5, "dw")
+    assert_close(bg.grad, b64.grad.float(), 1e-5, "db")
