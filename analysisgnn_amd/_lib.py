@@ -42,6 +42,14 @@ class Gated(C.Structure):
                 ("H", C.c_int32)]
 
 
+PACK_MAX_SRC = 8
+
+
+class PackItem(C.Structure):
+    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p * PACK_MAX_SRC), ("ld_dst", C.c_int64), ("ld_src", C.c_int64),
+                ("rows", C.c_int32), ("cols", C.c_int32), ("n_src", C.c_int32), ("vec_ok", C.c_int32)]
+
+
 _lib: Optional[C.CDLL] = None
 
 # every exported symbol of include/agnn.h: (name, restype, argtypes)
@@ -79,6 +87,7 @@ SIGNATURES = {
     "agnn_wgrad_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "agnn_wgrad_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "agnn_pack_f32": (C.c_int, [C.c_int32, C.POINTER(PackItem), C.c_void_p]),
     "agnn_gproj_fwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "agnn_gproj_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),

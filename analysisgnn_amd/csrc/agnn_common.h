@@ -48,6 +48,13 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_mov<0x140>(v);
   return v;
 }
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  return v;
+}
 __device__ __forceinline__ float wave_sum_dpp(float v) {
   v = row16_sum(v);
   return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));

@@ -18,6 +18,7 @@ namespace {
 constexpr int HH = 128;        // hidden size per direction
 constexpr int NT = 512;        // threads per chain: 64 unit-pairs x 8 k-chunks
 constexpr int KC = 8;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float dpp_xor1(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
@@ -53,7 +54,7 @@ __device__ __forceinline__ float tanhf_(float x) { return 2.f * __builtin_amdgcn
 __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, const float* __restrict__ w_hh,
                                                 const float* __restrict__ b_hh, int T, float* __restrict__ y,
                                                 float* __restrict__ saved) {
-  __shared__ __attribute__((aligned(16))) float hbuf[2][HH];
+  __shared__ __attribute__((aligned(16))) float hbuf[2][HH + NT];       // [HH, HH + NT): dummy slots
   const int b = blockIdx.x >> 1, d = blockIdx.x & 1;
   const int tid = threadIdx.x, g = tid >> 3, kc = tid & 7;
   const int u0 = 2 * g;
@@ -75,38 +76,35 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
 #pragma unroll
   for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
-    for (int q = 0; q < 2; ++q) bh[gate][q] = b_hh[d * 3 * HH + gate * HH + u0 + q];
+    for (int q = 0; q < 2; ++q) bh[gate][q] = kc == 0 ? b_hh[d * 3 * HH + gate * HH + u0 + q] : 0.f;
   if (tid < HH) { hbuf[0][tid] = 0.f; hbuf[1][tid] = 0.f; }
   float hprev[2] = {0.f, 0.f};
   __syncthreads();
 
   const size_t row3 = static_cast<size_t>(2) * 3 * HH;
-  auto gi_ptr = [&](int t) { return gi + (static_cast<size_t>(b) * T + t) * row3 + static_cast<size_t>(d) * 3 * HH + u0; };
-  int t = d ? T - 1 : 0;
-  float gin[3][2];
-  {
-    const float* p = gi_ptr(t);
+  // The loop body is branch-free on purpose.  With an `if (kc == 0)` around the stores the compiler lost count of the
+  // outstanding memory operations at the join and waited for ALL of them (s_waitcnt vmcnt(0)) in every step, i.e.
+  // for the input-projection load issued a few hundred cycles earlier: each step cost one full memory round trip
+  // (0.87 us).  Now every lane issues exactly one global store per step (lane kc of a unit-pair group stores
+  // h / r / z / n / W_hn h; lanes 5-7 repeat lane 4's store), all lanes write the same h to LDS, and the input
+  // projections are fetched FOUR steps ahead into a register ring (clamped index instead of a guard).
+  auto load_gi = [&](int s_, float (&g3)[3][2]) {
+    const int sc = s_ < T ? s_ : T - 1;
+    const int t_ = d ? T - 1 - sc : sc;
+    const float* p = gi + (static_cast<size_t>(b) * T + t_) * row3 + static_cast<size_t>(d) * 3 * HH + u0;
 #pragma unroll
     for (int gate = 0; gate < 3; ++gate) {
       const float2 v = *reinterpret_cast<const float2*>(p + gate * HH);
-      gin[gate][0] = v.x; gin[gate][1] = v.y;
+      g3[gate][0] = v.x; g3[gate][1] = v.y;
     }
-  }
-  for (int s = 0; s < T; ++s) {
+  };
+  const int h_slot = kc < 2 ? u0 + kc : HH + tid;
+  const int ks = kc < 4 ? kc : 4;                         // which of the 5 per-step outputs this lane stores
+  float* const st_base = ks == 0 ? y + d * HH + u0 : saved + static_cast<size_t>(d) * 4 * HH + static_cast<size_t>(ks - 1) * HH + u0;
+  const size_t st_stride = ks == 0 ? static_cast<size_t>(2) * HH : static_cast<size_t>(2) * 4 * HH;
+  auto step = [&](int s, float (&gin)[3][2]) {
     const int cur = s & 1;
-    const int tn = d ? t - 1 : t + 1;
-    float gnext[3][2];
-    if (s + 1 < T) {                       // prefetch next step's input projection
-      const float* p = gi_ptr(tn);
-#pragma unroll
-      for (int gate = 0; gate < 3; ++gate) {
-        const float2 v = *reinterpret_cast<const float2*>(p + gate * HH);
-        gnext[gate][0] = v.x; gnext[gate][1] = v.y;
-      }
-    } else {
-#pragma unroll
-      for (int gate = 0; gate < 3; ++gate) gnext[gate][0] = gnext[gate][1] = 0.f;
-    }
+    const int t = d ? T - 1 - s : s;
     float hk[16];
     {
       const float4* hp = reinterpret_cast<const float4*>(&hbuf[cur][16 * kc]);
@@ -121,13 +119,15 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
     for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        float a0 = 0.f, a1 = 0.f;
+        // packed fp32 FMA (v_pk_fma_f32): even / odd k in the two halves; the bias rides in lane kc == 0's accumulator
+        f32x2 acc = {bh[gate][q], 0.f};
 #pragma unroll
         for (int k = 0; k < 16; k += 2) {
-          a0 = fmaf(w[gate][q][k], hk[k], a0);
-          a1 = fmaf(w[gate][q][k + 1], hk[k + 1], a1);
+          const f32x2 wv = {w[gate][q][k], w[gate][q][k + 1]};
+          const f32x2 hv = {hk[k], hk[k + 1]};
+          acc = __builtin_elementwise_fma(wv, hv, acc);
         }
-        gh[gate][q] = group8_sum(a0 + a1) + bh[gate][q];
+        gh[gate][q] = group8_sum(acc.x + acc.y);
       }
     float hnew[2], rr[2], zz[2], nn[2];
 #pragma unroll
@@ -138,21 +138,31 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
       hnew[q] = (1.f - zz[q]) * nn[q] + zz[q] * hprev[q];
       hprev[q] = hnew[q];
     }
-    if (kc == 0) {
-      *reinterpret_cast<float2*>(&hbuf[cur ^ 1][u0]) = make_float2(hnew[0], hnew[1]);
-      const size_t bt = static_cast<size_t>(b) * T + t;
-      *reinterpret_cast<float2*>(y + bt * 2 * HH + d * HH + u0) = make_float2(hnew[0], hnew[1]);
-      float* sv = saved + (bt * 2 + d) * 4 * HH + u0;
-      *reinterpret_cast<float2*>(sv + 0 * HH) = make_float2(rr[0], rr[1]);
-      *reinterpret_cast<float2*>(sv + 1 * HH) = make_float2(zz[0], zz[1]);
-      *reinterpret_cast<float2*>(sv + 2 * HH) = make_float2(nn[0], nn[1]);
-      *reinterpret_cast<float2*>(sv + 3 * HH) = make_float2(gh[2][0], gh[2][1]);
-    }
-#pragma unroll
-    for (int gate = 0; gate < 3; ++gate) { gin[gate][0] = gnext[gate][0]; gin[gate][1] = gnext[gate][1]; }
-    t = tn;
+    // lanes kc = 0 / 1 write the pair's two h values, the others a private dummy slot: no exec-mask branch and no
+    // same-address write conflict (LDS serialises lanes that WRITE one address)
+    hbuf[cur ^ 1][h_slot] = kc == 1 ? hnew[1] : hnew[0];
+    float2 sv2;
+    sv2.x = ks == 0 ? hnew[0] : (ks == 1 ? rr[0] : (ks == 2 ? zz[0] : (ks == 3 ? nn[0] : gh[2][0])));
+    sv2.y = ks == 0 ? hnew[1] : (ks == 1 ? rr[1] : (ks == 2 ? zz[1] : (ks == 3 ? nn[1] : gh[2][1])));
+    *reinterpret_cast<float2*>(st_base + (static_cast<size_t>(b) * T + t) * st_stride) = sv2;
+    load_gi(s + 4, gin);                                    // refill this ring slot
     lds_barrier();
+  };
+  float g0[3][2], g1[3][2], g2[3][2], g3[3][2];
+  load_gi(0, g0);
+  load_gi(1, g1);
+  load_gi(2, g2);
+  load_gi(3, g3);
+  int s = 0;
+  for (; s + 4 <= T; s += 4) {
+    step(s, g0);
+    step(s + 1, g1);
+    step(s + 2, g2);
+    step(s + 3, g3);
   }
+  if (s < T) step(s, g0);
+  if (s + 1 < T) step(s + 1, g1);
+  if (s + 2 < T) step(s + 2, g2);
 }
 
 // dy [B,T,2*HH]; y, saved from the forward; outputs dgi [B,T,2,3*HH] (d r_pre, d z_pre, d n_pre) and
@@ -222,18 +232,20 @@ __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, co
       *reinterpret_cast<float2*>(&dgh[cur][2 * HH + u0]) = make_float2(dq[0], dq[1]);
     }
     lds_barrier();
-    float a[2] = {0.f, 0.f}, c[2] = {0.f, 0.f};
+    // packed fp32 FMA (v_pk_fma_f32): even / odd rows j of W^T in the two halves of each accumulator
+    f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
     const float4* gp = reinterpret_cast<const float4*>(&dgh[cur][JC * kc]);
 #pragma unroll
     for (int v = 0; v < JC / 4; ++v) {
       const float4 t4 = gp[v];
-      a[0] = fmaf(wt[0][4 * v + 0], t4.x, a[0]); a[1] = fmaf(wt[1][4 * v + 0], t4.x, a[1]);
-      c[0] = fmaf(wt[0][4 * v + 1], t4.y, c[0]); c[1] = fmaf(wt[1][4 * v + 1], t4.y, c[1]);
-      a[0] = fmaf(wt[0][4 * v + 2], t4.z, a[0]); a[1] = fmaf(wt[1][4 * v + 2], t4.z, a[1]);
-      c[0] = fmaf(wt[0][4 * v + 3], t4.w, c[0]); c[1] = fmaf(wt[1][4 * v + 3], t4.w, c[1]);
+      const f32x2 lo = {t4.x, t4.y}, hi = {t4.z, t4.w};
+      a0 = __builtin_elementwise_fma(f32x2{wt[0][4 * v + 0], wt[0][4 * v + 1]}, lo, a0);
+      a1 = __builtin_elementwise_fma(f32x2{wt[1][4 * v + 0], wt[1][4 * v + 1]}, lo, a1);
+      a0 = __builtin_elementwise_fma(f32x2{wt[0][4 * v + 2], wt[0][4 * v + 3]}, hi, a0);
+      a1 = __builtin_elementwise_fma(f32x2{wt[1][4 * v + 2], wt[1][4 * v + 3]}, hi, a1);
     }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) carry[q] = dh[q] * z[q] + group8_sum(a[q] + c[q]);
+    carry[0] = dh[0] * z[0] + group8_sum(a0.x + a0.y);
+    carry[1] = dh[1] * z[1] + group8_sum(a1.x + a1.y);
   }
 }
 

@@ -32,6 +32,7 @@ import torch.nn.functional as F
 from . import _lib, ops
 from .gru import gru_forward
 from .fused import FusedSequential, norm_act
+from .params import sage_operands
 from .linear import Linear, linear
 from .core_layers import JumpingKnowledge
 from .graph import HeteroIndex, hetero_index
@@ -142,10 +143,9 @@ class HeteroConv(nn.Module):
                                e_limit=[e_keep[et] for et in ets] if e_keep is not None else None)
             A = ops.aggregate(spec, [x_dict[s] for s in src_types])                      # [n, R*H]
             convs = [self.convs[et_key(et)] for et in ets]
-            W_l = torch.cat([c.lin_l.weight for c in convs], dim=1)                       # [out, R*H]
-            b = sum(c.lin_l.bias for c in convs)
-            W_r = sum(c.lin_r.weight for c in convs)
-            y = linear(A, W_l, b) + linear(x_dict[d][:n], W_r)
+            W_l, b, W_r = sage_operands([c.lin_l.weight for c in convs], [c.lin_l.bias for c in convs],
+                                        [c.lin_r.weight for c in convs])                 # [out, R*H], [out], [out, H]
+            y = linear(x_dict[d][:n], W_r, None, acc=linear(A, W_l, b))                   # second GEMM accumulates (beta = 1)
             out[d] = y / len(ets) if self.aggr == "mean" else y
         return out
 

@@ -43,9 +43,12 @@ def weight_grad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool):
 
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, acc):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
+        if acc is not None:                       # y = acc + x W^T (+ b): the GEMM's beta = 1 epilogue, no separate add
+            y = torch.addmm(acc, x, w.t())
+            return y + b if b is not None else y
         return torch.addmm(b, x, w.t()) if b is not None else x @ w.t()
 
     @staticmethod
@@ -55,16 +58,18 @@ class _LinearFn(torch.autograd.Function):
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = weight_grad(dy, x, ctx.has_bias and ctx.needs_input_grad[2])
-        return dx, dw, db
+        return dx, dw, db, (dy if ctx.needs_input_grad[3] else None)
 
 
-def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, acc: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x W^T (+ b) (+ acc)."""
     if x.is_cuda and torch.is_grad_enabled() and (w.requires_grad or (b is not None and b.requires_grad)):
         if x.dim() == 2 and x.shape[0] >= MIN_ROWS:
-            return _LinearFn.apply(x, w, b)
-        if x.dim() == 3 and x.shape[0] * x.shape[1] >= MIN_ROWS:
-            return _LinearFn.apply(x.reshape(-1, x.shape[-1]), w, b).view(x.shape[0], x.shape[1], -1)
-    return F.linear(x, w, b)
+            return _LinearFn.apply(x, w, b, acc)
+        if x.dim() == 3 and x.shape[0] * x.shape[1] >= MIN_ROWS and acc is None:
+            return _LinearFn.apply(x.reshape(-1, x.shape[-1]), w, b, None).view(x.shape[0], x.shape[1], -1)
+    y = F.linear(x, w, b)
+    return y + acc if acc is not None else y
 
 
 class Linear(nn.Linear):

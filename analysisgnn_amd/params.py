@@ -1,0 +1,84 @@
+"""Per-relation parameters presented as ONE GEMM operand, and its gradient handed back per parameter, with one
+`agnn_pack_f32` launch per direction (instead of a cat, six adds and nine copies per fused HeteroConv layer).
+
+PyG `HeteroConv({et: SAGEConv})` (ref: analysisgnn/models/cadence.py:147-159,174) sums, per destination type,
+`lin_l_r(mean_r) + lin_r_r(x_dst)` over the relations r.  With the per-relation means side by side in A [N, R*in]:
+    sum_r lin_l_r(mean_r) = A @ cat_r(W_l_r, dim=1)^T + sum_r b_r ,      sum_r lin_r_r(x) = x @ (sum_r W_r_r)^T
+The parameters stay separate `nn.Parameter`s (state_dict unchanged); this module only builds the operands."""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+
+def pack(items: Sequence[Tuple[torch.Tensor, Sequence[torch.Tensor]]], device) -> None:
+    """items: (dst 2-D view, [src 2-D views of the same shape and row stride]);  dst = sum(srcs)."""
+    arr = (_lib.PackItem * len(items))()
+    for i, (dst, srcs) in enumerate(items):
+        if len(srcs) > _lib.PACK_MAX_SRC:
+            raise _lib.AgnnError(f"pack: {len(srcs)} sources (max {_lib.PACK_MAX_SRC})")
+        rows, cols = dst.shape
+        ld_src = srcs[0].stride(0) if rows > 1 else max(cols, 1)
+        for t in (dst, *srcs):
+            if t.dtype != torch.float32 or t.dim() != 2 or (cols > 1 and t.stride(1) != 1) or tuple(t.shape) != (rows, cols):
+                raise _lib.AgnnError("pack: fp32 2-D pieces of one shape with unit inner stride expected")
+        for k, t in enumerate(srcs):
+            if rows > 1 and t.stride(0) != ld_src:
+                raise _lib.AgnnError("pack: the sources of an item must share their row stride")
+            arr[i].src[k] = t.data_ptr()
+        arr[i].dst = dst.data_ptr()
+        arr[i].ld_dst = dst.stride(0) if rows > 1 else max(cols, 1)
+        arr[i].ld_src = ld_src
+        arr[i].rows, arr[i].cols, arr[i].n_src = rows, cols, len(srcs)
+    lib = _lib.load()
+    _lib.check(lib.agnn_pack_f32(len(items), arr, _lib.stream_ptr(device)), "agnn_pack_f32")
+
+
+class _SageOperands(torch.autograd.Function):
+    """(W_l [out, R*in], b [out], W_r [out, in]) from R x (lin_l.weight, lin_l.bias, lin_r.weight)."""
+
+    @staticmethod
+    def forward(ctx, R: int, *params):
+        w_l, b_l, w_r = params[:R], params[R:2 * R], params[2 * R:]
+        dev = _lib.require_gpu(*params)
+        out_f, in_f = w_l[0].shape
+        W_l = torch.empty((out_f, R * in_f), dtype=torch.float32, device=dev)
+        b = torch.empty((out_f,), dtype=torch.float32, device=dev)
+        W_r = torch.empty((out_f, in_f), dtype=torch.float32, device=dev)
+        items = [(W_l[:, r * in_f:(r + 1) * in_f], [w_l[r].detach()]) for r in range(R)]
+        items.append((b.view(1, -1), [t.detach().view(1, -1) for t in b_l]))
+        items.append((W_r, [t.detach() for t in w_r]))
+        pack(items, dev)
+        ctx.R = R
+        ctx.shape = (out_f, in_f)
+        return W_l, b, W_r
+
+    @staticmethod
+    def backward(ctx, dW_l, db, dW_r):
+        R = ctx.R
+        out_f, in_f = ctx.shape
+        dev = dW_l.device
+        G_l = torch.empty((R, out_f, in_f), dtype=torch.float32, device=dev)
+        G_b = torch.empty((R, out_f), dtype=torch.float32, device=dev)
+        G_r = torch.empty((R, out_f, in_f), dtype=torch.float32, device=dev)
+        dW_l, db, dW_r = _lib.f32c(dW_l), db.contiguous(), _lib.f32c(dW_r)
+        items = []
+        for r in range(R):
+            items.append((G_l[r], [dW_l[:, r * in_f:(r + 1) * in_f]]))
+            items.append((G_b[r].view(1, -1), [db.view(1, -1)]))
+            items.append((G_r[r], [dW_r]))
+        pack(items, dev)
+        # unbind: one contiguous tensor per parameter (distinct memory, so each .grad can be taken over as is)
+        return (None, *G_l.unbind(0), *G_b.unbind(0), *G_r.unbind(0))
+
+
+def sage_operands(w_l: List[torch.Tensor], b_l: List[torch.Tensor], w_r: List[torch.Tensor]):
+    R = len(w_l)
+    ok = (w_l[0].is_cuda and R <= _lib.PACK_MAX_SRC and all(t is not None for t in b_l)
+          and all(t.shape == w_l[0].shape and t.is_contiguous() for t in (*w_l, *w_r)))
+    if not ok:
+        return torch.cat(w_l, dim=1), (sum(b_l) if all(t is not None for t in b_l) else None), sum(w_r)
+    return _SageOperands.apply(R, *w_l, *b_l, *w_r)

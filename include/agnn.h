@@ -18,6 +18,7 @@
  *   agnn_gated_*          `ResGatedGraphConv` edge gate + scatter (ref: core/gnn.py:246-257)
  *   agnn_norm_act_*       LayerNorm / ReLU / Dropout chains between the projections (ref: models/analysis.py:429-443)
  *   agnn_wgrad_f32        weight/bias gradients of the dense projections (fp32 MFMA, split over N)
+ *   agnn_pack_f32         per-relation parameter cat / sum / gradient fan-out of the fused HeteroConv (ref: models/cadence.py:147-159)
  *   agnn_gproj_*          the task heads' last Linear layers as one grouped projection (ref: models/analysis.py:486-496)
  *   agnn_multitask_ce_f32 the 21 per-task CrossEntropyLoss terms (ref: models/analysis.py:881-888)
  *   agnn_hgt_attn_*       PyG `HGTConv` message/softmax/aggregate, reached through graphmuse
@@ -247,6 +248,24 @@ size_t agnn_wgrad_workspace_bytes(int64_t n, int32_t out_f, int32_t in_f);
 int agnn_wgrad_f32(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, int64_t n, int32_t out_f,
                    int32_t in_f, float* dw, int64_t ld_dw, float* db, void* workspace, size_t workspace_bytes,
                    agnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Batched small 2-D gather / sum, one launch for many parameter-sized pieces:
+ *     dst_i[r, c] = sum_{k < n_src_i} src_{i,k}[r, c]        r < rows_i, c < cols_i
+ * Used to present per-relation parameters as one GEMM operand (PyG HeteroConv over SAGEConv: the lin_l weights side by
+ * side, lin_r weights and biases summed — ref: models/cadence.py:147-159,174) and to split / fan out the operand's
+ * gradient again.  All sources of an item share ld_src.  Destinations of different items must not overlap.
+ * `vec_ok` is filled in by the library.  Items are read on the host during the call.
+ * ------------------------------------------------------------------------------------------ */
+#define AGNN_PACK_MAX_SRC   8
+#define AGNN_PACK_MAX_ITEMS 24
+typedef struct {
+  float* dst;                               /* (device) */
+  const float* src[AGNN_PACK_MAX_SRC];      /* (device) */
+  int64_t ld_dst, ld_src;
+  int32_t rows, cols, n_src, vec_ok;
+} agnn_pack_item_t;
+int agnn_pack_f32(int32_t n_items, const agnn_pack_item_t* items /* (host) */, agnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Grouped projection: the last Linear(h2 -> C_t) of all task heads in one launch per direction
