@@ -13,6 +13,7 @@ import torch.nn as nn
 from . import _lib, ops
 from .encoders import HybridGNN, MetricalGNN
 from .fused import FusedSequential, advance_rng
+from .embedding import embedding
 from .heads import fused_head_logits
 from .linear import Linear
 from .graph import SegSpec, build_csr
@@ -83,8 +84,8 @@ class TorchAnalysisGNN(nn.Module):
         if self.training:
             advance_rng(x_dict["note"].device)          # fresh dropout masks for this step (device-side counter)
         z_dict = dict(x_dict)
-        z_dict["note"] = torch.cat([z_dict["note"], self.pitch_embedding(pitch_spelling),
-                                    self.key_embedding(key_signature)], dim=-1)
+        z_dict["note"] = torch.cat([z_dict["note"], embedding(pitch_spelling, self.pitch_embedding.weight),
+                                    embedding(key_signature, self.key_embedding.weight)], dim=-1)
         h_dict = {k: self.project_dict[k](z_dict[k]) for k in self.project_dict.keys()}
         x = self.encoder(x_dict=h_dict, edge_index_dict=edge_index_dict, batch_dict=batch_dict,
                          batch_size=batch_size, neighbor_mask_node=neighbor_mask_node,

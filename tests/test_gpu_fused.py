@@ -101,3 +101,20 @@ def test_grouped_norm_act_matches_per_task_layernorm():
     assert_close(xg.grad, xr.grad, 1e-4, "dx")
     assert_close(gg.grad, gr.grad, 1e-4, "dgamma")
     assert_close(bg.grad, br.grad, 1e-4, "dbeta")
+
+
+def test_small_embedding_backward_matches_library():
+    """analysisgnn_amd.embedding: onehot^T @ dY against torch's sort-based embedding backward (35- and 15-row tables)."""
+    from analysisgnn_amd.embedding import embedding
+    torch.manual_seed(0)
+    for V, N in ((35, 5000), (15, 4097), (35, 100)):
+        w = torch.randn(V, 64, device=DEV, requires_grad=True)
+        w2 = w.detach().clone().requires_grad_(True)
+        idx = torch.randint(0, V, (N,), device=DEV)
+        g = torch.randn(N, 64, device=DEV)
+        out = embedding(idx, w)
+        out.backward(g)
+        ref = F.embedding(idx, w2)
+        ref.backward(g)
+        assert torch.equal(out, ref)
+        assert_close(w.grad, w2.grad, 1e-5, f"dW V={V} N={N}")
