@@ -91,7 +91,10 @@ class FlatGradBuffer:
             self._packed = False
 
     def pack(self) -> None:
-        """views=False: gather the fresh gradients into the flat buffer (one launch)."""
+        """views=False: gather the fresh gradients into the flat buffer (one launch).  Also the join point of the
+        weight-gradient stream (linear.enable_wgrad_overlap)."""
+        from .linear import join_wgrad
+        join_wgrad()
         if self.views or getattr(self, "_packed", False):
             return
         self._packed = True
@@ -152,6 +155,13 @@ class FlatAdamW:
         self.v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
         denom = (self.v.sqrt() / bc2.sqrt()).add_(self.eps)
         self.flat.addcdiv_(self.m / bc1, denom, value=-self.lr)
+
+
+def enable_wgrad_overlap(flag: bool = True, scope: str = "all") -> None:
+    """Issue weight-gradient GEMMs on their own HIP stream (joined in FlatGradBuffer.pack).  Requires gradients to be
+    None when backward starts — FlatGradBuffer(views=False).zero() — see linear.py."""
+    from . import linear
+    linear.enable_wgrad_overlap(flag, scope)
 
 
 def barrier_and_sync() -> None:

@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
-from .linear import weight_grad
+from .linear import weight_grad, wgrad_stream
 
 MAX_ROWS = 256      # beyond this a one-hot operand is the wrong tool; fall back to the library op
 
@@ -20,6 +20,7 @@ class _SmallEmbedding(torch.autograd.Function):
     def forward(ctx, idx, weight):
         ctx.save_for_backward(idx)
         ctx.rows = weight.shape[0]
+        ctx.leaf = weight.is_leaf
         return F.embedding(idx, weight)
 
     @staticmethod
@@ -27,11 +28,13 @@ class _SmallEmbedding(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         V = ctx.rows
         Vp = V + (V & 1)                                                   # even width for the kernel
-        flat_idx = idx.reshape(-1)
-        onehot = (flat_idx.unsqueeze(1) == torch.arange(Vp, device=idx.device)).to(dy.dtype)   # [N, Vp]
-        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
-        dw, _ = weight_grad(onehot, dy2, False)                            # [Vp, D]
-        return None, dw[:V]
+        with wgrad_stream(dy.device, dy, idx, active=ctx.leaf):             # optimizer-only output (linear.py)
+            flat_idx = idx.reshape(-1)
+            onehot = (flat_idx.unsqueeze(1) == torch.arange(Vp, device=idx.device)).to(dy.dtype)   # [N, Vp]
+            dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+            dw, _ = weight_grad(onehot, dy2, False)                        # [Vp, D]
+            dw = dw[:V]
+        return None, dw
 
 
 def embedding(idx: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:

@@ -11,7 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .linear import weight_grad
+from .linear import mark_wgrad_async, weight_grad, wgrad_stream
 
 KERNEL_HIDDEN = 128
 
@@ -34,6 +34,7 @@ class _GRULayer(torch.autograd.Function):
                                         y.data_ptr(), saved.data_ptr(), _lib.stream_ptr(dev)), "agnn_gru_fwd_f32")
         ctx.save_for_backward(x2, w_ih, w_hh_c, y, saved)
         ctx.dims = (B, T, I, Hh)
+        ctx.wg_async = all(getattr(t, "_agnn_wgrad_async", False) or t.is_leaf for t in (w_ih, w_hh, b_ih, b_hh))
         return y
 
     @staticmethod
@@ -49,18 +50,20 @@ class _GRULayer(torch.autograd.Function):
                                         dgi.data_ptr(), dhn.data_ptr(), _lib.stream_ptr(dev)), "agnn_gru_bwd_f32")
         dgi2 = dgi.view(B * T, 6 * Hh)
         wf = w_ih.reshape(6 * Hh, I)
+        # everything that only feeds the optimizer leaves the recurrence chain (layer l-1's kernel waits for dx alone)
+        with wgrad_stream(dev, dgi, dhn, y, x2, active=ctx.wg_async, kind="sequence"):
+            dw_ih, db_ih = weight_grad(dgi2, x2, True)
+            dw_ih, db_ih = dw_ih.view(2, 3 * Hh, I), db_ih.view(2, 3 * Hh)
+            dgh = torch.cat([dgi[..., : 2 * Hh], dhn], dim=-1)                          # [B,T,2,3H]
+            hp = torch.zeros((B, T, 2, Hh), dtype=torch.float32, device=dev)             # h_{t-1} per direction
+            if T > 1:
+                hp[:, 1:, 0] = y[:, :-1, :Hh]
+                hp[:, :-1, 1] = y[:, 1:, Hh:]
+            dgh2, hp2 = dgh.view(B * T, 6 * Hh), hp.view(B * T, 2 * Hh)
+            parts = [weight_grad(dgh2[:, d * 3 * Hh:(d + 1) * 3 * Hh], hp2[:, d * Hh:(d + 1) * Hh], True) for d in range(2)]
+            dw_hh = torch.stack([p[0] for p in parts])
+            db_hh = torch.stack([p[1] for p in parts])
         dx = (dgi2 @ wf).view(B, T, I) if ctx.needs_input_grad[0] else None
-        dw_ih, db_ih = weight_grad(dgi2, x2, True)
-        dw_ih, db_ih = dw_ih.view(2, 3 * Hh, I), db_ih.view(2, 3 * Hh)
-        dgh = torch.cat([dgi[..., : 2 * Hh], dhn], dim=-1)                              # [B,T,2,3H]
-        hp = torch.zeros((B, T, 2, Hh), dtype=torch.float32, device=dev)                 # h_{t-1} per direction
-        if T > 1:
-            hp[:, 1:, 0] = y[:, :-1, :Hh]
-            hp[:, :-1, 1] = y[:, 1:, Hh:]
-        dgh2, hp2 = dgh.view(B * T, 6 * Hh), hp.view(B * T, 2 * Hh)
-        parts = [weight_grad(dgh2[:, d * 3 * Hh:(d + 1) * 3 * Hh], hp2[:, d * Hh:(d + 1) * Hh], True) for d in range(2)]
-        dw_hh = torch.stack([p[0] for p in parts])
-        db_hh = torch.stack([p[1] for p in parts])
         return dx, dw_ih, dw_hh, db_ih, db_hh
 
 
@@ -79,10 +82,11 @@ def gru_forward(rnn: nn.GRU, x: torch.Tensor, training: bool) -> torch.Tensor:
     for layer in range(rnn.num_layers):
         def p(n, layer=layer):
             return getattr(rnn, f"{n}_l{layer}"), getattr(rnn, f"{n}_l{layer}_reverse")
-        w_ih = torch.stack(p("weight_ih"))
-        w_hh = torch.stack(p("weight_hh"))
-        b_ih = torch.stack(p("bias_ih"))
-        b_hh = torch.stack(p("bias_hh"))
+        # torch.stack of leaf parameters: its backward is unbind (views, no kernel), so the gradients may arrive late
+        w_ih = mark_wgrad_async(torch.stack(p("weight_ih")))
+        w_hh = mark_wgrad_async(torch.stack(p("weight_hh")))
+        b_ih = mark_wgrad_async(torch.stack(p("bias_ih")))
+        b_hh = mark_wgrad_async(torch.stack(p("bias_hh")))
         y = _GRULayer.apply(y.contiguous(), w_ih, w_hh, b_ih, b_hh)
         if layer < rnn.num_layers - 1 and rnn.dropout > 0 and training:
             y = F.dropout(y, rnn.dropout, True)

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .fused import grouped_norm_act
-from .linear import linear
+from .linear import linear, mark_wgrad_async, wgrad_stream
 
 
 def fused_head_logits(clf_dict: nn.ModuleDict, x: torch.Tensor, tasks: Sequence[str]) -> Tuple[torch.Tensor, List[int]]:
@@ -29,8 +29,9 @@ def fused_head_logits(clf_dict: nn.ModuleDict, x: torch.Tensor, tasks: Sequence[
     mods = [clf_dict[t] for t in tasks]
     T = len(mods)
     h2 = mods[0][0].out_features
-    W1 = torch.cat([m[0].weight for m in mods], dim=0)                    # [T*h2, o]
-    b1 = torch.cat([m[0].bias for m in mods], dim=0)
+    # cat / stack of leaf parameters: their backward is narrow / unbind (views), so these gradients may arrive late
+    W1 = mark_wgrad_async(torch.cat([m[0].weight for m in mods], dim=0))  # [T*h2, o]
+    b1 = mark_wgrad_async(torch.cat([m[0].bias for m in mods], dim=0))
     a = linear(x, W1, b1)                                                 # [N, T*h2]
     gamma = torch.stack([m[2].weight for m in mods])                      # [T, h2]
     beta = torch.stack([m[2].bias for m in mods])
@@ -41,8 +42,8 @@ def fused_head_logits(clf_dict: nn.ModuleDict, x: torch.Tensor, tasks: Sequence[
     b2 = torch.cat([m[3].bias for m in mods], dim=0)
     a = a.reshape(-1, T * h2)
     if a.is_cuda and h2 in GPROJ_K and T <= _lib.MAX_SEG and GPROJ_ENABLED:
-        W2 = torch.cat([m[3].weight for m in mods], dim=0)                # [sum C, h2]
-        logits = grouped_projection(a, W2, b2, offs, h2)
+        W2 = mark_wgrad_async(torch.cat([m[3].weight for m in mods], dim=0))   # [sum C, h2]
+        logits = grouped_projection(a, W2, mark_wgrad_async(b2), offs, h2)
     else:                                                                 # widths the kernel is not built for
         W2 = torch.block_diag(*[m[3].weight for m in mods])               # [sum C, T*h2]
         logits = linear(a, W2, b2)
@@ -65,6 +66,7 @@ class _GroupedProj(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, w, b, offs_t, offs, K):
         dev = _lib.require_gpu(a, w, offs_t)
+        ctx._wg_async_in = all(t is None or t.is_leaf or getattr(t, "_agnn_wgrad_async", False) for t in (w, b))
         a = _lib.f32c(a)
         w = _lib.f32c(w)
         if w.data_ptr() % 16:
@@ -80,6 +82,7 @@ class _GroupedProj(torch.autograd.Function):
                                           out.data_ptr(), out.stride(0), _lib.stream_ptr(dev)), "agnn_gproj_fwd_f32")
         ctx.save_for_backward(a, w, offs_t)
         ctx.meta = (G, K, tiles, sum_c, b is not None)
+        ctx.wg_async = ctx._wg_async_in
         return out
 
     @staticmethod
@@ -90,15 +93,23 @@ class _GroupedProj(torch.autograd.Function):
         dout = _lib.f32c(dout)
         N = a.shape[0]
         lib = _lib.load()
-        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
         need_w = ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2])
-        dw = torch.empty_like(w) if need_w else None
-        db = torch.empty((sum_c,), dtype=torch.float32, device=dev) if (need_w and has_b) else None
-        nws = int(lib.agnn_gproj_workspace_bytes(N, sum_c, K, tiles)) if need_w else 0
-        ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=dev)
-        _lib.check(lib.agnn_gproj_bwd_f32(dout.data_ptr(), dout.stride(0), a.data_ptr(), a.stride(0), w.data_ptr(), offs_t.data_ptr(),
-                                          G, K, tiles, sum_c, N, _lib.ptr(da), da.stride(0) if da is not None else 0, _lib.ptr(dw),
-                                          _lib.ptr(db), ws.data_ptr(), nws, _lib.stream_ptr(dev)), "agnn_gproj_bwd_f32")
+        dw = db = None
+        if need_w:                                   # optimizer-only outputs: weight-gradient stream (linear.py)
+            with wgrad_stream(dev, dout, a, active=ctx.wg_async):
+                dw = torch.empty_like(w)
+                db = torch.empty((sum_c,), dtype=torch.float32, device=dev) if has_b else None
+                nws = int(lib.agnn_gproj_workspace_bytes(N, sum_c, K, tiles))
+                ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=dev)
+                _lib.check(lib.agnn_gproj_bwd_f32(dout.data_ptr(), dout.stride(0), a.data_ptr(), a.stride(0), w.data_ptr(),
+                                                  offs_t.data_ptr(), G, K, tiles, sum_c, N, None, 0, dw.data_ptr(), _lib.ptr(db),
+                                                  ws.data_ptr(), nws, _lib.stream_ptr(dev)), "agnn_gproj_bwd_f32")
+        da = None
+        if ctx.needs_input_grad[0]:
+            da = torch.empty_like(a)
+            _lib.check(lib.agnn_gproj_bwd_f32(dout.data_ptr(), dout.stride(0), a.data_ptr(), a.stride(0), w.data_ptr(),
+                                              offs_t.data_ptr(), G, K, tiles, sum_c, N, da.data_ptr(), da.stride(0), None, None,
+                                              None, 0, _lib.stream_ptr(dev)), "agnn_gproj_bwd_f32")
         return da, dw, db, None, None, None
 
 

@@ -18,6 +18,75 @@ MAX_OUT_IN = 512 * 1024  # above this output size the library GEMM (large tiles,
 ENABLED = True           # A/B switch for benchmarking
 
 
+# ------------------------------------------------------------------------------------------------------------
+# Weight gradients off the back-propagation chain.  dW / db of a projection are needed only by the optimizer, yet in
+# stream order they sit between a layer's dX and the next layer's backward.  With `enable_wgrad_overlap()` they are
+# issued on a second HIP stream (forked where dY is ready) and joined once, before the gradients are gathered
+# (`join_wgrad()`, called by dp.FlatGradBuffer.pack).  Only for weights whose gradient is consumed WITHOUT a kernel on
+# the launching stream: leaf parameters whose .grad is None when backward starts (FlatGradBuffer(views=False)) and
+# operands marked by `mark_wgrad_async` (built by kernel-free views or by ops that handle the stream themselves).
+# ------------------------------------------------------------------------------------------------------------
+_WG = {"enabled": False, "scope": "all", "streams": {}, "dirty": set()}
+
+
+def enable_wgrad_overlap(flag: bool = True, scope: str = "all") -> None:
+    """scope "all": every projection; "sequence": only the GRU layers' weight-gradient work (the recurrence chain)."""
+    _WG["enabled"] = bool(flag)
+    _WG["scope"] = scope
+
+
+def wgrad_overlap_enabled() -> bool:
+    return _WG["enabled"]
+
+
+def mark_wgrad_async(t: torch.Tensor) -> torch.Tensor:
+    """Declare that the gradient of this (non-leaf) operand is consumed without kernels on the launching stream."""
+    t._agnn_wgrad_async = True
+    return t
+
+
+def _async_ok(t: Optional[torch.Tensor]) -> bool:
+    return t is None or t.is_leaf or getattr(t, "_agnn_wgrad_async", False)
+
+
+class wgrad_stream:
+    """`with wgrad_stream(dev, *inputs):` runs the body on the weight-gradient stream (after everything queued so far on
+    the current stream) and keeps `inputs` alive for it; a no-op context when the overlap is disabled."""
+
+    def __init__(self, dev, *inputs, active: bool = True, kind: str = "linear"):
+        self.on = bool(_WG["enabled"] and active and torch.device(dev).type == "cuda" and (_WG["scope"] == "all" or kind == _WG["scope"]))
+        self.dev, self.inputs = torch.device(dev), inputs
+
+    def __enter__(self):
+        if not self.on:
+            return self
+        idx = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        ws = _WG["streams"].get(idx)
+        if ws is None:
+            ws = _WG["streams"][idx] = torch.cuda.Stream(device=self.dev)
+        ws.wait_stream(torch.cuda.current_stream(self.dev))
+        self.ws = ws
+        self.ctx = torch.cuda.stream(ws)
+        self.ctx.__enter__()
+        _WG["dirty"].add(idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+            for t in self.inputs:
+                if t is not None:
+                    t.record_stream(self.ws)
+        return False
+
+
+def join_wgrad() -> None:
+    """Make the current stream wait for all weight-gradient work issued so far (no host sync)."""
+    for idx in list(_WG["dirty"]):
+        torch.cuda.current_stream(idx).wait_stream(_WG["streams"][idx])
+    _WG["dirty"].clear()
+
+
 def _ok(t: torch.Tensor) -> bool:
     return (t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 2 == 0
             and t.shape[1] % 2 == 0 and t.data_ptr() % 8 == 0)
@@ -46,6 +115,7 @@ class _LinearFn(torch.autograd.Function):
     def forward(ctx, x, w, b, acc):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
+        ctx.wg_async = _async_ok(w) and _async_ok(b)
         if acc is not None:                       # y = acc + x W^T (+ b): the GEMM's beta = 1 epilogue, no separate add
             y = torch.addmm(acc, x, w.t())
             return y + b if b is not None else y
@@ -54,10 +124,11 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        dx = dy @ w if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, db = weight_grad(dy, x, ctx.has_bias and ctx.needs_input_grad[2])
+            with wgrad_stream(dy.device, dy, x, active=ctx.wg_async):     # forked before dX is queued: both start at once
+                dw, db = weight_grad(dy, x, ctx.has_bias and ctx.needs_input_grad[2])
+        dx = dy @ w if ctx.needs_input_grad[0] else None
         return dx, dw, db, (dy if ctx.needs_input_grad[3] else None)
 
 

@@ -12,6 +12,7 @@ from typing import List, Sequence, Tuple
 import torch
 
 from . import _lib
+from .linear import mark_wgrad_async, wgrad_stream
 
 
 def pack(items: Sequence[Tuple[torch.Tensor, Sequence[torch.Tensor]]], device) -> None:
@@ -54,6 +55,7 @@ class _SageOperands(torch.autograd.Function):
         pack(items, dev)
         ctx.R = R
         ctx.shape = (out_f, in_f)
+        ctx.leaves = all(t.is_leaf for t in params)
         return W_l, b, W_r
 
     @staticmethod
@@ -64,13 +66,15 @@ class _SageOperands(torch.autograd.Function):
         G_l = torch.empty((R, out_f, in_f), dtype=torch.float32, device=dev)
         G_b = torch.empty((R, out_f), dtype=torch.float32, device=dev)
         G_r = torch.empty((R, out_f, in_f), dtype=torch.float32, device=dev)
-        dW_l, db, dW_r = _lib.f32c(dW_l), db.contiguous(), _lib.f32c(dW_r)
-        items = []
-        for r in range(R):
-            items.append((G_l[r], [dW_l[:, r * in_f:(r + 1) * in_f]]))
-            items.append((G_b[r].view(1, -1), [db.view(1, -1)]))
-            items.append((G_r[r], [dW_r]))
-        pack(items, dev)
+        # the incoming gradients may have been produced on the weight-gradient stream: fan them out there as well
+        with wgrad_stream(dev, dW_l, db, dW_r, active=ctx.leaves):
+            dW_l, db, dW_r = _lib.f32c(dW_l), db.contiguous(), _lib.f32c(dW_r)
+            items = []
+            for r in range(R):
+                items.append((G_l[r], [dW_l[:, r * in_f:(r + 1) * in_f]]))
+                items.append((G_b[r].view(1, -1), [db.view(1, -1)]))
+                items.append((G_r[r], [dW_r]))
+            pack(items, dev)
         # unbind: one contiguous tensor per parameter (distinct memory, so each .grad can be taken over as is)
         return (None, *G_l.unbind(0), *G_b.unbind(0), *G_r.unbind(0))
 
@@ -81,4 +85,8 @@ def sage_operands(w_l: List[torch.Tensor], b_l: List[torch.Tensor], w_r: List[to
           and all(t.shape == w_l[0].shape and t.is_contiguous() for t in (*w_l, *w_r)))
     if not ok:
         return torch.cat(w_l, dim=1), (sum(b_l) if all(t is not None for t in b_l) else None), sum(w_r)
-    return _SageOperands.apply(R, *w_l, *b_l, *w_r)
+    ops_ = _SageOperands.apply(R, *w_l, *b_l, *w_r)
+    if all(t.is_leaf for t in (*w_l, *b_l, *w_r)):
+        for t in ops_:
+            mark_wgrad_async(t)
+    return ops_

@@ -103,6 +103,7 @@ def main():
                     help="c2 (default, the BASELINE metric): HybridGNN L=3 H=256; c3: HGT L=3 H=256 heads=4 with beat+measure "
                          "nodes, 6 relation types; c5: MetricalGNN L=4 H=512, heads cadence/localkey/romanNumeral")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying hipGraphs")
+    ap.add_argument("--no-wgrad-overlap", action="store_true", help="A/B only: weight gradients on the main stream")
     ap.add_argument("--library-wgrad", action="store_true", help="A/B only: weight gradients through the library GEMM")
     ap.add_argument("--blas", default=None, choices=[None, "hipblaslt", "rocblas"], help="A/B only: torch's preferred BLAS library")
     args = ap.parse_args()
@@ -143,6 +144,7 @@ def main():
     model = TorchAnalysisGNN(g.metadata(), IN_CH, hid, OUT, TASK_DICT, layers, dropout=0.3, use_jk=False,
                              encoder_type=enc).to(dev).train()
     flat = dp.FlatGradBuffer(model.parameters(), views=False)
+    dp.enable_wgrad_overlap(not args.no_wgrad_overlap, os.environ.get("AGNN_WG_SCOPE", "sequence"))             # weight-gradient GEMMs on their own stream, joined in flat.pack()
     opt = dp.FlatAdamW(model.parameters(), flat, lr=5e-3, weight_decay=5e-3)     # analysis.py:1380-1381 hyper-parameters
     graph.index_cache_enabled = False                               # fresh batch every step: rebuild the CSR
 

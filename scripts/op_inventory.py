@@ -29,4 +29,4 @@ torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=False) as prof:
     step(); torch.cuda.synchronize()
-print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=40, max_shapes_column_width=70))
+print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=300, max_name_column_width=40, max_shapes_column_width=70))

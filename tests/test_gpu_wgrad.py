@@ -53,3 +53,38 @@ def test_linear_module_gradients():
     assert_close(m.weight.grad, ref.weight.grad, 1e-4)
     assert_close(m.bias.grad, ref.bias.grad, 1e-4)
     assert_close(x.grad, xr.grad, 1e-4)
+
+
+def test_wgrad_stream_overlap_gives_identical_gradients():
+    """One training step of the C2-shaped model (small) with weight gradients on their own stream vs on the launching
+    stream: every parameter gradient bit-identical (same kernels, same order of summation)."""
+    from analysisgnn_amd import dp, linear
+    from analysisgnn_amd.heads import multitask_cross_entropy
+    from analysisgnn_amd.models import TorchAnalysisGNN
+    from analysisgnn_amd.synth import make_batch, torch_inputs
+    tasks = {"a": 4, "b": 50, "c": 185, "d": 2}
+    g = make_batch(8, 300)
+    I = torch_inputs(g, 25, "cuda:0", seed=0)
+    labels = torch.stack([torch.randint(0, c, (I["batch_size"],), generator=torch.Generator().manual_seed(i)).to("cuda:0")
+                          for i, c in enumerate(tasks.values())])
+    grads = []
+    for overlap in (False, True):
+        torch.manual_seed(0)
+        model = TorchAnalysisGNN(g.metadata(), 25, 256, 128, tasks, 2, dropout=0.0, use_jk=False).to("cuda:0").train()
+        flat = dp.FlatGradBuffer(model.parameters(), views=False)
+        dp.enable_wgrad_overlap(overlap)
+        try:
+            flat.zero()
+            x = model.encode(I["pitch_spelling"], I["key_signature"], I["x_dict"], I["edge_index_dict"], I["batch_dict"],
+                             I["batch_size"], None, None)
+            logits, offs, _ = model.forward_clf_fused(x)
+            loss = 0.1 * x.pow(2).mean() + multitask_cross_entropy(logits, offs, labels, 0.1, -1).sum()
+            loss.backward()
+            flat.pack()
+            torch.cuda.synchronize()
+            grads.append(flat.flat.clone())
+        finally:
+            dp.enable_wgrad_overlap(False)
+    assert torch.isfinite(grads[0]).all()
+    assert grads[0].abs().max() > 0
+    assert torch.equal(grads[0], grads[1])
