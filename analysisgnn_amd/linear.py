@@ -94,20 +94,28 @@ def _ok(t: torch.Tensor) -> bool:
 
 def weight_grad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool):
     """(dW [out, in], db [out] or None) for dy [N, out], x [N, in] on the HIP kernel; library GEMM when the
-    shape / alignment does not fit the kernel."""
+    shape / alignment does not fit the kernel.  An odd `in` is served when x has a spare (zero) column behind its last
+    one — rows padded to an even stride, as models.encode lays out the 153-wide note input: the kernel then runs on
+    in + 1 columns and the extra gradient column is dropped."""
     n, out_f = dy.shape
     in_f = x.shape[1]
-    if not (ENABLED and dy.is_cuda and n >= MIN_ROWS and out_f * in_f <= MAX_OUT_IN and _ok(dy) and _ok(x)):
+    in_k = in_f
+    if in_f & 1 and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) > in_f:
+        in_k = in_f + 1
+        x = x.as_strided((n, in_k), (x.stride(0), 1), x.storage_offset())
+    if not (ENABLED and dy.is_cuda and n >= MIN_ROWS and out_f * in_k <= MAX_OUT_IN and _ok(dy) and _ok(x)):
+        if in_k != in_f:
+            x = x[:, :in_f]
         return dy.t() @ x, (dy.sum(dim=0) if want_bias else None)
     lib = _lib.load()
     dev = dy.device
-    dw = torch.empty((out_f, in_f), dtype=torch.float32, device=dev)
+    dw = torch.empty((out_f, in_k), dtype=torch.float32, device=dev)
     db = torch.empty((out_f,), dtype=torch.float32, device=dev) if want_bias else None
-    nws = int(lib.agnn_wgrad_workspace_bytes(n, out_f, in_f))
+    nws = int(lib.agnn_wgrad_workspace_bytes(n, out_f, in_k))
     ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-    _lib.check(lib.agnn_wgrad_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), n, out_f, in_f, dw.data_ptr(),
+    _lib.check(lib.agnn_wgrad_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), n, out_f, in_k, dw.data_ptr(),
                                   dw.stride(0), _lib.ptr(db), ws.data_ptr(), nws, _lib.stream_ptr(dev)), "agnn_wgrad_f32")
-    return dw, db
+    return (dw if in_k == in_f else dw[:, :in_f]), db
 
 
 class _LinearFn(torch.autograd.Function):

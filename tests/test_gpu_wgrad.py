@@ -88,3 +88,22 @@ def test_wgrad_stream_overlap_gives_identical_gradients():
     assert torch.isfinite(grads[0]).all()
     assert grads[0].abs().max() > 0
     assert torch.equal(grads[0], grads[1])
+
+
+def test_weight_grad_odd_width_with_padded_rows():
+    """in = 153 (25 features + two 64-wide embeddings) on rows padded to 156 floats: served by the kernel on 154 columns."""
+    from analysisgnn_amd import linear
+    torch.manual_seed(0)
+    n = 4099
+    buf = torch.zeros(n, 156, device="cuda:0")
+    buf[:, :153] = torch.randn(n, 153, device="cuda:0")
+    x = buf[:, :153]
+    dy = torch.randn(n, 256, device="cuda:0")
+    dw, db = linear.weight_grad(dy, x, True)
+    ref = dy.double().t() @ x.double()
+    assert dw.shape == (256, 153)
+    assert_close(dw, ref.float(), 1e-5, "dw odd")
+    assert_close(db, dy.double().sum(0).float(), 1e-5, "db")
+    xc = x.contiguous()                                  # no spare column: library path
+    dw2, _ = linear.weight_grad(dy, xc, False)
+    assert_close(dw2, ref.float(), 1e-5, "dw odd (library)")
