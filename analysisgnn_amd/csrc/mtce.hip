@@ -7,7 +7,7 @@
 // tasks in one pass, the per-row loss terms and the FINAL gradient w.r.t. the logits (already divided by
 // the number of non-ignored rows of the task), so backward is a scale by the incoming scalar.
 //   p = softmax(z);  loss_row = (1-eps) * (-log p_y) + eps * (-(1/C) sum_c log p_c)
-//   dz_c = inv_cnt[t] * (p_c - (1-eps) [c == y] - eps / C)        (rows with y == ignore: 0)
+//   dz_c = p_c - (1-eps) [c == y] - eps / C        (rows with y == ignore: 0); scaled per task by k_mtce_scale
 // Memory-bound: reads and writes the logits matrix once.  No atomics: per-row losses go to [N, T] and are
 // summed by the caller in a fixed order.
 #include <cmath>
@@ -59,8 +59,7 @@ __device__ __forceinline__ void task_regs(const float* __restrict__ zr, float* _
 
 __global__ __launch_bounds__(256) void k_mtce(const float* __restrict__ z, int64_t ld, const int32_t* __restrict__ off, int T,
                                               const int64_t* __restrict__ labels, int64_t n_rows, float eps, int64_t ignore,
-                                              const float* __restrict__ inv_cnt, float* __restrict__ row_loss,
-                                              float* __restrict__ dz) {
+                                              float* __restrict__ row_loss, float* __restrict__ dz) {
   const int lane = threadIdx.x & 63, sub = lane & 15;
   const int64_t row_raw = (static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
   if (row_raw >= n_rows) return;                            // whole 16-lane rows drop out; DPP never crosses a row
@@ -73,7 +72,7 @@ __global__ __launch_bounds__(256) void k_mtce(const float* __restrict__ z, int64
     if (C <= 0) continue;
     const int64_t y = labels[static_cast<int64_t>(t) * n_rows + row];
     const bool valid = (y != ignore);
-    const float sc = valid ? inv_cnt[t] : 0.f;
+    const float sc = valid ? 1.f : 0.f;              // per-task 1/count and the incoming gradient are applied by k_mtce_scale
     float loss;
     const int nk = (C + 15) >> 4;
     if (nk == 1) task_regs<1>(zr, dr, a, b, sub, y, valid, sc, eps, loss);
@@ -101,7 +100,52 @@ __global__ __launch_bounds__(256) void k_mtce(const float* __restrict__ z, int64
         dr[c] = sc * (p - (((c - a) == y ? 1.f - eps : 0.f) + sm));
       }
     }
-    if (sub == 0) row_loss[row * T + t] = loss;
+    if (sub == 0) row_loss[static_cast<int64_t>(t) * n_rows + row] = loss;     // task-major: the reduction reads contiguously
+  }
+}
+
+// loss[t] = sum_n row_loss[t][n] / max(count_t, 1),  inv_cnt[t] = 1 / max(count_t, 1),  count_t = #{n : labels[t][n] != ignore}.
+// One block per task, fixed-order tree: bitwise reproducible.
+__global__ __launch_bounds__(256) void k_mtce_reduce(const float* __restrict__ row_loss, const int64_t* __restrict__ labels, int64_t n_rows,
+                                                     int64_t ignore, float* __restrict__ loss, float* __restrict__ inv_cnt) {
+  __shared__ float sl[256];
+  __shared__ int sc[256];
+  const int t = blockIdx.x;
+  const float* rl = row_loss + static_cast<int64_t>(t) * n_rows;
+  const int64_t* lb = labels + static_cast<int64_t>(t) * n_rows;
+  float a = 0.f;
+  int c = 0;
+  for (int64_t i = threadIdx.x; i < n_rows; i += 256) {
+    a += rl[i];
+    c += lb[i] != ignore ? 1 : 0;
+  }
+  sl[threadIdx.x] = a;
+  sc[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (static_cast<int>(threadIdx.x) < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float inv = 1.f / static_cast<float>(sc[0] > 0 ? sc[0] : 1);
+    loss[t] = sl[0] * inv;
+    inv_cnt[t] = inv;
+  }
+}
+
+// out[n, c] = dz[n, c] * scale[task(c)] for the columns of the T segments (float4 over whole rows when aligned)
+__global__ __launch_bounds__(256) void k_mtce_scale(const float* __restrict__ dz, int64_t ld, const int32_t* __restrict__ off, int T,
+                                                    int64_t n_rows, const float* __restrict__ scale, float* __restrict__ out, int64_t ld_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const float* zr = dz + row * ld;
+  float* orow = out + row * ld_out;
+  const int width = off[T];
+  int t = 0;
+  for (int c = lane; c < width; c += 64) {
+    while (c >= off[t + 1]) ++t;                      // columns ascend per lane: the task index only moves forward
+    orow[c] = c >= off[0] ? zr[c] * scale[t] : zr[c];
   }
 }
 
@@ -109,14 +153,28 @@ __global__ __launch_bounds__(256) void k_mtce(const float* __restrict__ z, int64
 
 extern "C" int agnn_multitask_ce_f32(const float* logits, int64_t ld, const int32_t* seg_off, int32_t n_tasks,
                                      const int64_t* labels, int64_t n_rows, float label_smoothing, int64_t ignore_index,
-                                     const float* inv_count, float* row_loss, float* dlogits, agnn_stream_t stream_) {
+                                     float* row_loss, float* dlogits, float* loss, float* inv_count, agnn_stream_t stream_) {
   using namespace agnn;
   if (n_rows < 0 || n_tasks < 0 || ld < 0) return fail(AGNN_EINVAL, "multitask_ce: negative size");
   if (n_rows == 0 || n_tasks == 0) return AGNN_OK;
-  if (!logits || !seg_off || !labels || !inv_count || !row_loss || !dlogits) return fail(AGNN_EINVAL, "multitask_ce: null argument");
+  if (!logits || !seg_off || !labels || !row_loss || !dlogits || !loss || !inv_count) return fail(AGNN_EINVAL, "multitask_ce: null argument");
   if (label_smoothing < 0.f || label_smoothing >= 1.f) return fail(AGNN_EINVAL, "multitask_ce: label_smoothing=%f", label_smoothing);
   const unsigned blocks = static_cast<unsigned>((n_rows + 15) / 16);   // 4 waves x 4 rows
-  hipLaunchKernelGGL(k_mtce, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_), logits, ld, seg_off, n_tasks,
-                     labels, n_rows, label_smoothing, ignore_index, inv_count, row_loss, dlogits);
-  return check_launch("multitask_ce");
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  hipLaunchKernelGGL(k_mtce, dim3(blocks), dim3(256), 0, s, logits, ld, seg_off, n_tasks, labels, n_rows, label_smoothing,
+                     ignore_index, row_loss, dlogits);
+  if (int rc = check_launch("multitask_ce")) return rc;
+  hipLaunchKernelGGL(k_mtce_reduce, dim3(n_tasks), dim3(256), 0, s, row_loss, labels, n_rows, ignore_index, loss, inv_count);
+  return check_launch("multitask_ce_reduce");
+}
+
+extern "C" int agnn_multitask_ce_scale_f32(const float* dlogits, int64_t ld, const int32_t* seg_off, int32_t n_tasks, int64_t n_rows,
+                                           const float* scale, float* out, int64_t ld_out, agnn_stream_t stream_) {
+  using namespace agnn;
+  if (n_rows < 0 || n_tasks < 0) return fail(AGNN_EINVAL, "multitask_ce_scale: negative size");
+  if (n_rows == 0 || n_tasks == 0) return AGNN_OK;
+  if (!dlogits || !seg_off || !scale || !out) return fail(AGNN_EINVAL, "multitask_ce_scale: null argument");
+  hipLaunchKernelGGL(k_mtce_scale, dim3(static_cast<unsigned>((n_rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     dlogits, ld, seg_off, n_tasks, n_rows, scale, out, ld_out);
+  return check_launch("multitask_ce_scale");
 }

@@ -141,12 +141,27 @@ class FlatAdamW:
         self.v = torch.zeros_like(self.flat)
 
     @torch.no_grad()
-    def step(self) -> None:
-        """Graph-capturable: the step counter and the bias corrections live on the device."""
-        b1, b2 = self.betas
-        g = self.grads.flat
+    def step(self, max_norm: float = 0.0) -> None:
+        """One AdamW update; `max_norm > 0` first clips the global gradient norm (clip_grad_norm_ semantics).
+        Graph-capturable: the step counter and the bias corrections live on the device.  On a GPU the whole thing is
+        the two launches of `agnn_adamw_f32`; on CPU tensors (gloo tests) the same arithmetic in torch ops."""
         if not hasattr(self, "_t"):
             self._t = torch.zeros((), dtype=torch.float32, device=self.flat.device)
+        g = self.grads.flat
+        if self.flat.is_cuda:
+            from . import _lib
+            lib = _lib.load()
+            if not hasattr(self, "_ws"):
+                self._ws = torch.empty(int(lib.agnn_adamw_workspace_bytes()), dtype=torch.uint8, device=self.flat.device)
+                self.last_norm = torch.zeros((), dtype=torch.float32, device=self.flat.device)
+            _lib.check(lib.agnn_adamw_f32(self.flat.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.flat.numel(),
+                                          float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd),
+                                          float(max_norm), self._t.data_ptr(), self.last_norm.data_ptr(), 0, self._ws.data_ptr(),
+                                          self._ws.numel(), _lib.stream_ptr(self.flat.device)), "agnn_adamw_f32")
+            return
+        if max_norm > 0:
+            self.grads.clip_norm_(max_norm)
+        b1, b2 = self.betas
         self._t += 1.0
         bc1 = 1.0 - (b1 ** self._t)
         bc2 = 1.0 - (b2 ** self._t)

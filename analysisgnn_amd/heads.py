@@ -120,37 +120,44 @@ def grouped_projection(a: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tenso
 
 class _MultiTaskCE(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, labels, offs_t, eps: float, ignore_index: int):
+    def forward(ctx, logits, labels, offs_t, eps: float, ignore_index: int, full_cover: bool = False):
         dev = _lib.require_gpu(logits, labels, offs_t)
         if logits.dtype != torch.float32 or logits.stride(1) != 1:
             logits = logits.float().contiguous()
         N = logits.shape[0]
         T = offs_t.numel() - 1
         labels = labels.contiguous()
-        cnt = (labels != ignore_index).sum(dim=1).clamp(min=1).to(torch.float32)
-        inv_cnt = 1.0 / cnt
-        row_loss = torch.empty((N, T), dtype=torch.float32, device=dev)
-        dlogits = torch.zeros_like(logits) if offs_t.numel() and logits.shape[1] != 0 else logits
+        row_loss = torch.empty((T, N), dtype=torch.float32, device=dev)
+        loss = torch.zeros((T,), dtype=torch.float32, device=dev)
+        inv_cnt = torch.ones((T,), dtype=torch.float32, device=dev)
+        # the kernel writes every column of every segment: zero-fill only when the segments leave columns uncovered
+        dlogits = torch.empty_like(logits) if full_cover else torch.zeros_like(logits)
         lib = _lib.load()
         _lib.check(lib.agnn_multitask_ce_f32(logits.data_ptr(), logits.stride(0), offs_t.data_ptr(), T, labels.data_ptr(), N,
-                                             float(eps), int(ignore_index), inv_cnt.data_ptr(), row_loss.data_ptr(),
-                                             dlogits.data_ptr(), _lib.stream_ptr(dev)), "agnn_multitask_ce_f32")
-        ctx.save_for_backward(dlogits, offs_t)
-        return row_loss.sum(dim=0) * inv_cnt                                # [T] mean loss per task
+                                             float(eps), int(ignore_index), row_loss.data_ptr(), dlogits.data_ptr(),
+                                             loss.data_ptr(), inv_cnt.data_ptr(), _lib.stream_ptr(dev)), "agnn_multitask_ce_f32")
+        ctx.save_for_backward(dlogits, offs_t, inv_cnt)
+        return loss                                                        # [T] mean loss per task
 
     @staticmethod
     def backward(ctx, g):
-        dlogits, offs_t = ctx.saved_tensors
-        width = dlogits.shape[1]
-        seg = torch.bucketize(torch.arange(width, device=g.device, dtype=torch.int32), offs_t[1:], right=True)
-        gcol = g[seg.clamp(max=g.numel() - 1)]
-        return dlogits * gcol.unsqueeze(0), None, None, None, None
+        dlogits, offs_t, inv_cnt = ctx.saved_tensors
+        dev = dlogits.device
+        T = offs_t.numel() - 1
+        scale = (g.to(torch.float32) * inv_cnt).contiguous()
+        out = torch.empty_like(dlogits)
+        lib = _lib.load()
+        _lib.check(lib.agnn_multitask_ce_scale_f32(dlogits.data_ptr(), dlogits.stride(0), offs_t.data_ptr(), T, dlogits.shape[0],
+                                                   scale.data_ptr(), out.data_ptr(), out.stride(0), _lib.stream_ptr(dev)),
+                   "agnn_multitask_ce_scale_f32")
+        return out, None, None, None, None, None
 
 
 def multitask_cross_entropy(logits: torch.Tensor, offs: Sequence[int], labels: torch.Tensor, label_smoothing: float = 0.1,
                             ignore_index: int = -1) -> torch.Tensor:
     """Per-task mean losses [T] for side-by-side logits [N, sum C]; labels int64 [T, N]."""
-    return _MultiTaskCE.apply(logits, labels, _offs_tensor(offs, logits.device), label_smoothing, ignore_index)
+    full = len(offs) > 1 and offs[0] == 0 and offs[-1] == logits.shape[1] and all(offs[i] < offs[i + 1] for i in range(len(offs) - 1))
+    return _MultiTaskCE.apply(logits, labels, _offs_tensor(offs, logits.device), label_smoothing, ignore_index, full)
 
 
 _OFFS_CACHE: Dict[tuple, torch.Tensor] = {}

@@ -164,8 +164,7 @@ def main():
         return loss
 
     def update():
-        flat.clip_norm_(1.0)
-        opt.step()
+        opt.step(max_norm=1.0)                                      # clip + AdamW: agnn_adamw_f32 (two launches)
 
     # The whole step is ~450 launches; issued one by one from Python they cost more host time than GPU time, so
     # the two launch sequences (forward+backward+gradient gather; clip+AdamW) are captured ONCE into hipGraphs and

@@ -20,6 +20,7 @@
  *   agnn_wgrad_f32        weight/bias gradients of the dense projections (fp32 MFMA, split over N)
  *   agnn_pack_f32         per-relation parameter cat / sum / gradient fan-out of the fused HeteroConv (ref: models/cadence.py:147-159)
  *   agnn_gproj_*          the task heads' last Linear layers as one grouped projection (ref: models/analysis.py:486-496)
+ *   agnn_adamw_f32        gradient clipping + `torch.optim.AdamW` step on the flat buffers (ref: models/analysis.py:1380-1381)
  *   agnn_multitask_ce_f32 the 21 per-task CrossEntropyLoss terms (ref: models/analysis.py:881-888)
  *   agnn_hgt_attn_*       PyG `HGTConv` message/softmax/aggregate, reached through graphmuse
  *                         `HybridHGT` (ref: models/analysis.py:445-453)
@@ -290,14 +291,35 @@ int agnn_gproj_bwd_f32(const float* dout, int64_t ld_dout, const float* a, int64
  * Fused multi-task cross entropy (label smoothing, ignore index) over column segments of one logits
  * matrix: replaces the per-task `nn.CrossEntropyLoss(ignore_index=-1, label_smoothing=0.1)` terms
  * (ref: models/analysis.py:881-888, models/chord.py:39-49).  Task t owns columns [seg_off[t], seg_off[t+1]).
- *   labels    int64 [n_tasks, n_rows]      inv_count [n_tasks] = 1 / max(#rows with label != ignore, 1)
- *   row_loss  [n_rows, n_tasks]  per-row loss terms (0 for ignored rows); task loss = sum * inv_count
- *   dlogits   [n_rows, ld]       d(sum_t mean-loss_t) / d logits  (columns outside the segments untouched)
+ *   labels    int64 [n_tasks, n_rows]
+ *   row_loss  [n_tasks, n_rows]  per-row loss terms (0 for ignored rows)                      (scratch output)
+ *   dlogits   [n_rows, ld]       d loss_row / d logits, NOT yet divided by the task's row count (ignored rows: 0;
+ *                                columns outside the segments untouched)
+ *   loss      [n_tasks]          mean loss per task = sum_n row_loss[t][n] / max(count_t, 1)
+ *   inv_count [n_tasks]          1 / max(count_t, 1), count_t = rows with label != ignore_index
+ * agnn_multitask_ce_scale_f32: out[n, c] = dlogits[n, c] * scale[task(c)] — the backward pass with
+ * scale[t] = inv_count[t] * (incoming gradient of loss[t]).
  * ------------------------------------------------------------------------------------------ */
 int agnn_multitask_ce_f32(const float* logits, int64_t ld, const int32_t* seg_off, int32_t n_tasks,
                           const int64_t* labels, int64_t n_rows, float label_smoothing,
-                          int64_t ignore_index, const float* inv_count, float* row_loss, float* dlogits,
+                          int64_t ignore_index, float* row_loss, float* dlogits, float* loss, float* inv_count,
                           agnn_stream_t stream);
+int agnn_multitask_ce_scale_f32(const float* dlogits, int64_t ld, const int32_t* seg_off, int32_t n_tasks,
+                                int64_t n_rows, const float* scale, float* out, int64_t ld_out, agnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Global-norm gradient clipping + AdamW over flat fp32 buffers (ref optimizer: models/analysis.py:1380-1381
+ * `torch.optim.AdamW`; clipping as Lightning's gradient_clip_val does before the step):
+ *     g' = g * min(max_norm / (||g||_2 + 1e-6), 1)            (max_norm <= 0: no clipping)
+ *     p  = p (1 - lr wd) - lr * (m' / (1 - b1^t)) / (sqrt(v') / sqrt(1 - b2^t) + eps),  m' = b1 m + (1-b1) g', v' = b2 v + (1-b2) g'^2
+ * `step` is a DEVICE float holding t-1; the call increments it (so a captured hipGraph advances it on replay).
+ * norm_out (device float, may be NULL) receives ||g||_2 before clipping.  write_clipped_grad != 0 stores g' back.
+ * Two launches, sums in a fixed order.  Buffers 16-byte aligned.
+ * ------------------------------------------------------------------------------------------ */
+size_t agnn_adamw_workspace_bytes(void);
+int agnn_adamw_f32(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, float max_norm, float* step, float* norm_out, int32_t write_clipped_grad,
+                   void* workspace, size_t workspace_bytes, agnn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -118,3 +118,28 @@ def test_small_embedding_backward_matches_library():
         ref.backward(g)
         assert torch.equal(out, ref)
         assert_close(w.grad, w2.grad, 1e-5, f"dW V={V} N={N}")
+
+
+def test_fused_clip_adamw_matches_torch():
+    """agnn_adamw_f32 (dp.FlatAdamW.step on a GPU) against clip_grad_norm_ + torch.optim.AdamW over several steps."""
+    from analysisgnn_amd import dp
+    torch.manual_seed(0)
+    a = nn.Sequential(nn.Linear(37, 64), nn.ReLU(), nn.Linear(64, 5)).to(DEV)
+    b = nn.Sequential(nn.Linear(37, 64), nn.ReLU(), nn.Linear(64, 5)).to(DEV)
+    b.load_state_dict(a.state_dict())
+    ref = torch.optim.AdamW(a.parameters(), lr=5e-3, weight_decay=5e-3)
+    flat = dp.FlatGradBuffer(b.parameters(), views=False)
+    opt = dp.FlatAdamW(b.parameters(), flat, lr=5e-3, weight_decay=5e-3)
+    x = torch.randn(64, 37, device=DEV)
+    for it in range(6):
+        ref.zero_grad(set_to_none=True)
+        (a(x).pow(2).sum() * 3.0).backward()
+        total = torch.nn.utils.clip_grad_norm_(a.parameters(), 0.5)
+        ref.step()
+        flat.zero()
+        (b(x).pow(2).sum() * 3.0).backward()
+        flat.pack()
+        opt.step(max_norm=0.5)
+        assert abs(float(opt.last_norm) - float(total)) <= 1e-4 * float(total)
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            torch.testing.assert_close(pb, pa, rtol=1e-4, atol=1e-6)
