@@ -81,15 +81,57 @@ def gru_forward(rnn: nn.GRU, x: torch.Tensor, training: bool) -> torch.Tensor:
     if not kernel_applicable(rnn):
         return rnn(x)[0]
     y = x
+    stacked = _stack_gru_params(rnn)
     for layer in range(rnn.num_layers):
-        def p(n, layer=layer):
-            return getattr(rnn, f"{n}_l{layer}"), getattr(rnn, f"{n}_l{layer}_reverse")
-        # torch.stack of leaf parameters: its backward is unbind (views, no kernel), so the gradients may arrive late
-        w_ih = mark_wgrad_async(torch.stack(p("weight_ih")))
-        w_hh = mark_wgrad_async(torch.stack(p("weight_hh")))
-        b_ih = mark_wgrad_async(torch.stack(p("bias_ih")))
-        b_hh = mark_wgrad_async(torch.stack(p("bias_hh")))
+        w_ih, w_hh, b_ih, b_hh = stacked[4 * layer:4 * layer + 4]
         y = _GRULayer.apply(y.contiguous(), w_ih, w_hh, b_ih, b_hh)
         if layer < rnn.num_layers - 1 and rnn.dropout > 0 and training:
             y = F.dropout(y, rnn.dropout, True)
     return y
+
+
+class _StackPairs(torch.autograd.Function):
+    """stack((forward, reverse)) of every GRU parameter of every layer in ONE `agnn_pack_f32` launch (torch.stack is a
+    launch per parameter, 8 per step, on the sequence branch's chain); backward hands out views of the incoming
+    gradients (no kernel), so the weight gradients may be produced late (linear.mark_wgrad_async)."""
+
+    @staticmethod
+    def forward(ctx, *params):
+        from .params import pack
+        dev = params[0].device
+        outs, items = [], []
+        for i in range(0, len(params), 2):
+            a, b = params[i], params[i + 1]
+            o = torch.empty((2,) + tuple(a.shape), dtype=torch.float32, device=dev)
+            outs.append(o)
+            for k, src in enumerate((a, b)):
+                src = src.detach()
+                items.append((o[k].reshape(1, -1) if src.dim() == 1 else o[k], [src.reshape(1, -1) if src.dim() == 1 else src]))
+        pack(items, dev)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        out = []
+        for g in grads:
+            out.extend(g.unbind(0))
+        return tuple(out)
+
+
+def _stack_gru_params(rnn: nn.GRU):
+    names = ("weight_ih", "weight_hh", "bias_ih", "bias_hh")
+    flat = []
+    for layer in range(rnn.num_layers):
+        for n in names:
+            flat.append(getattr(rnn, f"{n}_l{layer}"))
+            flat.append(getattr(rnn, f"{n}_l{layer}_reverse"))
+    if flat[0].is_cuda and all(t.is_contiguous() and t.dtype == torch.float32 for t in flat):
+        outs = _StackPairs.apply(*flat)
+        leaves = all(t.is_leaf for t in flat)
+    else:
+        outs = tuple(torch.stack((flat[i], flat[i + 1])) for i in range(0, len(flat), 2))
+        leaves = all(t.is_leaf for t in flat)
+    if leaves:
+        for o in outs:
+            mark_wgrad_async(o)
+    return outs
