@@ -106,23 +106,23 @@ __global__ __launch_bounds__(256) void k_mtce(const float* __restrict__ z, int64
 
 // loss[t] = sum_n row_loss[t][n] / max(count_t, 1),  inv_cnt[t] = 1 / max(count_t, 1),  count_t = #{n : labels[t][n] != ignore}.
 // One block per task, fixed-order tree: bitwise reproducible.
-__global__ __launch_bounds__(256) void k_mtce_reduce(const float* __restrict__ row_loss, const int64_t* __restrict__ labels, int64_t n_rows,
+__global__ __launch_bounds__(1024) void k_mtce_reduce(const float* __restrict__ row_loss, const int64_t* __restrict__ labels, int64_t n_rows,
                                                      int64_t ignore, float* __restrict__ loss, float* __restrict__ inv_cnt) {
-  __shared__ float sl[256];
-  __shared__ int sc[256];
+  __shared__ float sl[1024];
+  __shared__ int sc[1024];
   const int t = blockIdx.x;
   const float* rl = row_loss + static_cast<int64_t>(t) * n_rows;
   const int64_t* lb = labels + static_cast<int64_t>(t) * n_rows;
   float a = 0.f;
   int c = 0;
-  for (int64_t i = threadIdx.x; i < n_rows; i += 256) {
+  for (int64_t i = threadIdx.x; i < n_rows; i += 1024) {
     a += rl[i];
     c += lb[i] != ignore ? 1 : 0;
   }
   sl[threadIdx.x] = a;
   sc[threadIdx.x] = c;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
+  for (int o = 512; o > 0; o >>= 1) {
     if (static_cast<int>(threadIdx.x) < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
     __syncthreads();
   }
@@ -164,7 +164,7 @@ extern "C" int agnn_multitask_ce_f32(const float* logits, int64_t ld, const int3
   hipLaunchKernelGGL(k_mtce, dim3(blocks), dim3(256), 0, s, logits, ld, seg_off, n_tasks, labels, n_rows, label_smoothing,
                      ignore_index, row_loss, dlogits);
   if (int rc = check_launch("multitask_ce")) return rc;
-  hipLaunchKernelGGL(k_mtce_reduce, dim3(n_tasks), dim3(256), 0, s, row_loss, labels, n_rows, ignore_index, loss, inv_count);
+  hipLaunchKernelGGL(k_mtce_reduce, dim3(n_tasks), dim3(1024), 0, s, row_loss, labels, n_rows, ignore_index, loss, inv_count);
   return check_launch("multitask_ce_reduce");
 }
 
