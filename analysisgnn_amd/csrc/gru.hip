@@ -11,6 +11,8 @@
 // for all steps at once.  The backward kernel walks the chain in reverse with W_hh^T in
 // registers and emits dGI / dHN; weight gradients are library GEMMs over those.
 // fp32 throughout (v_exp/v_rcp gate functions, ~3 ulp), no atomics, bitwise reproducible run to run.
+#include <cstdlib>
+
 #include "agnn_common.h"
 
 namespace {
@@ -165,6 +167,129 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
   if (s + 2 < T) step(s + 2, g2);
 }
 
+// ---- two-phase forward -------------------------------------------------------------------------------------------
+// The kernel above is bound by instruction issue: every one of the 8 waves runs the whole step body (~250 instructions),
+// of which only 48 packed FMAs are the mat-vec — the gate math, address arithmetic, loads and stores are repeated by all
+// 8 lanes that share a unit pair.  Here a step has two phases:
+//   phase 1 (all 8 waves): h chunk from LDS, 48 packed FMAs, the six partial sums of the lane's k-chunk to LDS
+//            (part[kc][gate][unit], no cross-lane reduction at all);
+//   phase 2 (waves 0 and 1, one lane per hidden unit): add the 8 partials per gate in a fixed order, gates, h_t to LDS,
+//            the five per-step outputs to HBM (coalesced over units), prefetch of the input projections 4 steps ahead.
+// Two LDS-only barriers per step; waves 2-7 run a loop that contains phase 1 only (so the loop of the unit-lane waves is
+// straight-line code with unconditional loads / stores and counted s_waitcnt).  ~75 + ~90/4 instruction slots per
+// SIMD-wave pair instead of 2 x 250.
+constexpr int PSTR = 3 * HH + 16;      // row stride of part[kc]: 4-way (= minimal) bank spread for the 8-byte writes
+
+__global__ __launch_bounds__(NT) void k_gru_fwd2(const float* __restrict__ gi, const float* __restrict__ w_hh,
+                                                 const float* __restrict__ b_hh, int T, float* __restrict__ y,
+                                                 float* __restrict__ saved) {
+  __shared__ __attribute__((aligned(16))) float hbuf[2][HH];
+  __shared__ __attribute__((aligned(16))) float part[KC * PSTR];
+  const int b = blockIdx.x >> 1, d = blockIdx.x & 1;
+  const int tid = threadIdx.x, g = tid >> 3, kc = tid & 7;
+  const int u0 = 2 * g;
+  const float* W = w_hh + static_cast<size_t>(d) * 3 * HH * HH;
+  f32x2 w[3][2][8];
+#pragma unroll
+  for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float4* src = reinterpret_cast<const float4*>(W + static_cast<size_t>(gate * HH + u0 + q) * HH + 16 * kc);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float4 t4 = src[v];
+        w[gate][q][2 * v] = f32x2{t4.x, t4.y};
+        w[gate][q][2 * v + 1] = f32x2{t4.z, t4.w};
+      }
+    }
+  if (tid < HH) { hbuf[0][tid] = 0.f; hbuf[1][tid] = 0.f; }
+  __syncthreads();
+
+  auto phase1 = [&](int cur) {
+    f32x2 hk[8];
+    const float4* hp = reinterpret_cast<const float4*>(&hbuf[cur][16 * kc]);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float4 t4 = hp[v];
+      hk[2 * v] = f32x2{t4.x, t4.y};
+      hk[2 * v + 1] = f32x2{t4.z, t4.w};
+    }
+#pragma unroll
+    for (int gate = 0; gate < 3; ++gate) {
+      f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        a0 = __builtin_elementwise_fma(w[gate][0][k], hk[k], a0);
+        a1 = __builtin_elementwise_fma(w[gate][1][k], hk[k], a1);
+      }
+      *reinterpret_cast<float2*>(&part[kc * PSTR + gate * HH + u0]) = make_float2(a0.x + a0.y, a1.x + a1.y);
+    }
+  };
+
+  if (tid >= HH) {                       // waves 2..7: mat-vec only
+    for (int s = 0; s < T; ++s) {
+      phase1(s & 1);
+      lds_barrier();
+      lds_barrier();
+    }
+    return;
+  }
+
+  // waves 0, 1: lane = hidden unit
+  const int u = tid;
+  const float bh0 = b_hh[d * 3 * HH + u], bh1 = b_hh[d * 3 * HH + HH + u], bh2 = b_hh[d * 3 * HH + 2 * HH + u];
+  float hprev = 0.f;
+  const size_t row3 = static_cast<size_t>(2) * 3 * HH;
+  auto load_gi = [&](int s_, float (&g3)[3]) {
+    const int sc = s_ < T ? s_ : T - 1;
+    const int t_ = d ? T - 1 - sc : sc;
+    const float* p = gi + (static_cast<size_t>(b) * T + t_) * row3 + static_cast<size_t>(d) * 3 * HH + u;
+    g3[0] = p[0];
+    g3[1] = p[HH];
+    g3[2] = p[2 * HH];
+  };
+  auto phase2 = [&](int s, float (&gin)[3]) {
+    const int cur = s & 1;
+    const int t = d ? T - 1 - s : s;
+    float s0 = bh0, s1 = bh1, s2 = bh2;
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {       // fixed order: bitwise reproducible
+      s0 += part[k * PSTR + u];
+      s1 += part[k * PSTR + HH + u];
+      s2 += part[k * PSTR + 2 * HH + u];
+    }
+    const float rr = sigmoidf_(gin[0] + s0);
+    const float zz = sigmoidf_(gin[1] + s1);
+    const float nn = tanhf_(gin[2] + rr * s2);
+    const float hnew = (1.f - zz) * nn + zz * hprev;
+    hprev = hnew;
+    hbuf[cur ^ 1][u] = hnew;
+    const size_t bt = static_cast<size_t>(b) * T + t;
+    y[bt * 2 * HH + d * HH + u] = hnew;
+    float* sv = saved + (bt * 2 + d) * 4 * HH + u;
+    sv[0] = rr;
+    sv[HH] = zz;
+    sv[2 * HH] = nn;
+    sv[3 * HH] = s2;
+    load_gi(s + 4, gin);                 // refill this ring slot
+  };
+  float g0[3], g1[3], g2[3], g3[3];
+  load_gi(0, g0);
+  load_gi(1, g1);
+  load_gi(2, g2);
+  load_gi(3, g3);
+  int s = 0;
+  for (; s + 4 <= T; s += 4) {
+    phase1(s & 1);       lds_barrier(); phase2(s, g0);     lds_barrier();
+    phase1((s + 1) & 1); lds_barrier(); phase2(s + 1, g1); lds_barrier();
+    phase1((s + 2) & 1); lds_barrier(); phase2(s + 2, g2); lds_barrier();
+    phase1((s + 3) & 1); lds_barrier(); phase2(s + 3, g3); lds_barrier();
+  }
+  if (s < T)     { phase1(s & 1);       lds_barrier(); phase2(s, g0);     lds_barrier(); }
+  if (s + 1 < T) { phase1((s + 1) & 1); lds_barrier(); phase2(s + 1, g1); lds_barrier(); }
+  if (s + 2 < T) { phase1((s + 2) & 1); lds_barrier(); phase2(s + 2, g2); lds_barrier(); }
+}
+
 // dy [B,T,2*HH]; y, saved from the forward; outputs dgi [B,T,2,3*HH] (d r_pre, d z_pre, d n_pre) and
 // dhn [B,T,2,HH] (gradient of W_hn h + b_hn).
 __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, const float* __restrict__ y,
@@ -249,6 +374,110 @@ __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, co
   }
 }
 
+// ---- two-phase backward (same split as k_gru_fwd2) ------------------------------------------------------------------
+//   phase A (waves 0 and 1, one lane per hidden unit): carry = dh_{t+1} z_{t+1} + the 8 partial sums of W_hh^T dgh left
+//            by phase B of the previous step; gate gradients; dgi / dhn to HBM; the three dgh vectors to LDS;
+//   phase B (all 8 waves): 48 packed FMAs of the lane's 48-row chunk of W_hh^T, partial sums to LDS.
+__global__ __launch_bounds__(NT) void k_gru_bwd2(const float* __restrict__ dy, const float* __restrict__ y,
+                                                 const float* __restrict__ saved, const float* __restrict__ w_hh,
+                                                 int T, float* __restrict__ dgi, float* __restrict__ dhn_out) {
+  __shared__ __attribute__((aligned(16))) float dgh[3 * HH];
+  __shared__ __attribute__((aligned(16))) float cpart[KC * (HH + 16)];
+  constexpr int CSTR = HH + 16;
+  const int b = blockIdx.x >> 1, d = blockIdx.x & 1;
+  const int tid = threadIdx.x, g = tid >> 3, kc = tid & 7;
+  const int u0 = 2 * g;
+  const float* W = w_hh + static_cast<size_t>(d) * 3 * HH * HH;
+  constexpr int JC = 3 * HH / KC;   // 48 rows of W per lane chunk
+  f32x2 wa[JC / 2], wb[JC / 2];     // unit u0 / u0+1: (W[j][u], W[j+1][u]) pairs over the chunk's rows
+#pragma unroll
+  for (int j = 0; j < JC; j += 2) {
+    const float2 v0 = *reinterpret_cast<const float2*>(W + static_cast<size_t>(JC * kc + j) * HH + u0);
+    const float2 v1 = *reinterpret_cast<const float2*>(W + static_cast<size_t>(JC * kc + j + 1) * HH + u0);
+    wa[j / 2] = f32x2{v0.x, v1.x};
+    wb[j / 2] = f32x2{v0.y, v1.y};
+  }
+  for (int i = tid; i < KC * CSTR; i += NT) cpart[i] = 0.f;
+  __syncthreads();
+
+  auto phaseB = [&]() {
+    f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+    const float4* gp = reinterpret_cast<const float4*>(&dgh[JC * kc]);
+#pragma unroll
+    for (int v = 0; v < JC / 4; ++v) {
+      const float4 t4 = gp[v];
+      const f32x2 lo = {t4.x, t4.y}, hi = {t4.z, t4.w};
+      a0 = __builtin_elementwise_fma(wa[2 * v], lo, a0);
+      a1 = __builtin_elementwise_fma(wb[2 * v], lo, a1);
+      a0 = __builtin_elementwise_fma(wa[2 * v + 1], hi, a0);
+      a1 = __builtin_elementwise_fma(wb[2 * v + 1], hi, a1);
+    }
+    *reinterpret_cast<float2*>(&cpart[kc * CSTR + u0]) = make_float2(a0.x + a0.y, a1.x + a1.y);
+  };
+
+  if (tid >= HH) {                       // waves 2..7: mat-vec only
+    for (int s = 0; s < T; ++s) {
+      lds_barrier();
+      phaseB();
+      lds_barrier();
+    }
+    return;
+  }
+
+  const int u = tid;
+  struct StepIn { float dyv, r, z, n, q, hp; };
+  auto fetch = [&](int s_, StepIn& o) {
+    const int sc = s_ < T ? s_ : T - 1;
+    const int t_ = d ? sc : T - 1 - sc;          // reverse of the forward walk
+    const int tp_ = d ? t_ + 1 : t_ - 1;
+    const size_t bt_ = static_cast<size_t>(b) * T + t_;
+    o.dyv = dy[bt_ * 2 * HH + d * HH + u];
+    const float* sv = saved + (bt_ * 2 + d) * 4 * HH + u;
+    o.r = sv[0];
+    o.z = sv[HH];
+    o.n = sv[2 * HH];
+    o.q = sv[3 * HH];
+    const bool has_prev = tp_ >= 0 && tp_ < T;
+    const int tpc = has_prev ? tp_ : t_;
+    o.hp = y[(static_cast<size_t>(b) * T + tpc) * 2 * HH + d * HH + u] * (has_prev ? 1.f : 0.f);
+  };
+  float dhz = 0.f;
+  auto phaseA = [&](int s, StepIn& in) {
+    const int t = d ? s : T - 1 - s;
+    float carry = dhz;
+#pragma unroll
+    for (int k = 0; k < KC; ++k) carry += cpart[k * CSTR + u];          // fixed order
+    const float dh = in.dyv + carry;
+    const float dn = dh * (1.f - in.z);
+    const float dz = dh * (in.hp - in.n);
+    const float dnp = dn * (1.f - in.n * in.n);
+    const float dr = dnp * in.q;
+    const float dq = dnp * in.r;
+    const float dzp = dz * in.z * (1.f - in.z);
+    const float drp = dr * in.r * (1.f - in.r);
+    dhz = dh * in.z;
+    dgh[u] = drp;
+    dgh[HH + u] = dzp;
+    dgh[2 * HH + u] = dq;
+    const size_t bt = static_cast<size_t>(b) * T + t;
+    float* go = dgi + (bt * 2 + d) * 3 * HH + u;
+    go[0] = drp;
+    go[HH] = dzp;
+    go[2 * HH] = dnp;
+    dhn_out[(bt * 2 + d) * HH + u] = dq;
+    fetch(s + 2, in);                    // refill this register set
+  };
+  StepIn inA, inB;
+  fetch(0, inA);
+  fetch(1, inB);
+  int s = 0;
+  for (; s + 2 <= T; s += 2) {
+    phaseA(s, inA);     lds_barrier(); phaseB(); lds_barrier();
+    phaseA(s + 1, inB); lds_barrier(); phaseB(); lds_barrier();
+  }
+  if (s < T) { phaseA(s, inA); lds_barrier(); phaseB(); lds_barrier(); }
+}
+
 }  // namespace
 
 extern "C" int agnn_gru_fwd_f32(const float* gi, const float* w_hh, const float* b_hh, int64_t B, int64_t T,
@@ -259,8 +488,13 @@ extern "C" int agnn_gru_fwd_f32(const float* gi, const float* w_hh, const float*
   if (B == 0 || T == 0) return AGNN_OK;
   if (!gi || !w_hh || !b_hh || !y || !saved) return fail(AGNN_EINVAL, "gru_fwd: null argument");
   if (!aligned16(gi) || !aligned16(w_hh) || !aligned16(y) || !aligned16(saved)) return fail(AGNN_EALIGN, "gru_fwd: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL(k_gru_fwd, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), gi,
-                     w_hh, b_hh, static_cast<int>(T), y, saved);
+  static const bool v1 = getenv("AGNN_GRU_V1") != nullptr;          // A/B: the one-phase kernel
+  if (v1)
+    hipLaunchKernelGGL(k_gru_fwd, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), gi,
+                       w_hh, b_hh, static_cast<int>(T), y, saved);
+  else
+    hipLaunchKernelGGL(k_gru_fwd2, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), gi,
+                       w_hh, b_hh, static_cast<int>(T), y, saved);
   return check_launch("gru_fwd");
 }
 
@@ -272,7 +506,12 @@ extern "C" int agnn_gru_bwd_f32(const float* dy, const float* y, const float* sa
   if (B == 0 || T == 0) return AGNN_OK;
   if (!dy || !y || !saved || !w_hh || !dgi || !dhn) return fail(AGNN_EINVAL, "gru_bwd: null argument");
   if (!aligned16(dy) || !aligned16(y) || !aligned16(saved) || !aligned16(w_hh) || !aligned16(dgi) || !aligned16(dhn)) return fail(AGNN_EALIGN, "gru_bwd: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL(k_gru_bwd, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), dy, y,
-                     saved, w_hh, static_cast<int>(T), dgi, dhn);
+  static const bool v1 = getenv("AGNN_GRU_V1") != nullptr;          // A/B: the one-phase kernel
+  if (v1)
+    hipLaunchKernelGGL(k_gru_bwd, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), dy, y,
+                       saved, w_hh, static_cast<int>(T), dgi, dhn);
+  else
+    hipLaunchKernelGGL(k_gru_bwd2, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), dy, y,
+                       saved, w_hh, static_cast<int>(T), dgi, dhn);
   return check_launch("gru_bwd");
 }
