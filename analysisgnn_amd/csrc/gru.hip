@@ -171,14 +171,15 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
 // The kernel above is bound by instruction issue: every one of the 8 waves runs the whole step body (~250 instructions),
 // of which only 48 packed FMAs are the mat-vec — the gate math, address arithmetic, loads and stores are repeated by all
 // 8 lanes that share a unit pair.  Here a step has two phases:
-//   phase 1 (all 8 waves): h chunk from LDS, 48 packed FMAs, the six partial sums of the lane's k-chunk to LDS
-//            (part[kc][gate][unit], no cross-lane reduction at all);
+//   phase 1 (all 8 waves; wave = one 16-wide k chunk of W_hh, lane = six of its 384 rows): the wave's h chunk from LDS
+//            (one address for all lanes), 48 packed FMAs, six partial sums to LDS (part[kc][gate][unit], no cross-lane
+//            reduction at all);
 //   phase 2 (waves 0 and 1, one lane per hidden unit): add the 8 partials per gate in a fixed order, gates, h_t to LDS,
 //            the five per-step outputs to HBM (coalesced over units), prefetch of the input projections 4 steps ahead.
 // Two LDS-only barriers per step; waves 2-7 run a loop that contains phase 1 only (so the loop of the unit-lane waves is
 // straight-line code with unconditional loads / stores and counted s_waitcnt).  ~75 + ~90/4 instruction slots per
 // SIMD-wave pair instead of 2 x 250.
-constexpr int PSTR = 3 * HH + 16;      // row stride of part[kc]: 4-way (= minimal) bank spread for the 8-byte writes
+constexpr int PSTR = 3 * HH;           // part[kc][gate*HH + unit]
 
 __global__ __launch_bounds__(NT) void k_gru_fwd2(const float* __restrict__ gi, const float* __restrict__ w_hh,
                                                  const float* __restrict__ b_hh, int T, float* __restrict__ y,
@@ -186,28 +187,27 @@ __global__ __launch_bounds__(NT) void k_gru_fwd2(const float* __restrict__ gi, c
   __shared__ __attribute__((aligned(16))) float hbuf[2][HH];
   __shared__ __attribute__((aligned(16))) float part[KC * PSTR];
   const int b = blockIdx.x >> 1, d = blockIdx.x & 1;
-  const int tid = threadIdx.x, g = tid >> 3, kc = tid & 7;
-  const int u0 = 2 * g;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int kc = __builtin_amdgcn_readfirstlane(tid >> 6);       // this WAVE's k chunk: its h values are wave-uniform
   const float* W = w_hh + static_cast<size_t>(d) * 3 * HH * HH;
-  f32x2 w[3][2][8];
+  // lane -> the six rows {lane + 64 i} of W_hh (row = gate*HH + unit), columns [16 kc, 16 kc + 16)
+  f32x2 w[6][8];
 #pragma unroll
-  for (int gate = 0; gate < 3; ++gate)
+  for (int i = 0; i < 6; ++i) {
+    const float4* src = reinterpret_cast<const float4*>(W + static_cast<size_t>(lane + 64 * i) * HH + 16 * kc);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const float4* src = reinterpret_cast<const float4*>(W + static_cast<size_t>(gate * HH + u0 + q) * HH + 16 * kc);
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const float4 t4 = src[v];
-        w[gate][q][2 * v] = f32x2{t4.x, t4.y};
-        w[gate][q][2 * v + 1] = f32x2{t4.z, t4.w};
-      }
+    for (int v = 0; v < 4; ++v) {
+      const float4 t4 = src[v];
+      w[i][2 * v] = f32x2{t4.x, t4.y};
+      w[i][2 * v + 1] = f32x2{t4.z, t4.w};
     }
+  }
   if (tid < HH) { hbuf[0][tid] = 0.f; hbuf[1][tid] = 0.f; }
   __syncthreads();
 
   auto phase1 = [&](int cur) {
     f32x2 hk[8];
-    const float4* hp = reinterpret_cast<const float4*>(&hbuf[cur][16 * kc]);
+    const float4* hp = reinterpret_cast<const float4*>(&hbuf[cur][16 * kc]);      // same address in every lane: LDS broadcast
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const float4 t4 = hp[v];
@@ -215,14 +215,11 @@ __global__ __launch_bounds__(NT) void k_gru_fwd2(const float* __restrict__ gi, c
       hk[2 * v + 1] = f32x2{t4.z, t4.w};
     }
 #pragma unroll
-    for (int gate = 0; gate < 3; ++gate) {
-      f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+    for (int i = 0; i < 6; ++i) {
+      f32x2 a = {0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        a0 = __builtin_elementwise_fma(w[gate][0][k], hk[k], a0);
-        a1 = __builtin_elementwise_fma(w[gate][1][k], hk[k], a1);
-      }
-      *reinterpret_cast<float2*>(&part[kc * PSTR + gate * HH + u0]) = make_float2(a0.x + a0.y, a1.x + a1.y);
+      for (int k = 0; k < 8; ++k) a = __builtin_elementwise_fma(w[i][k], hk[k], a);
+      part[kc * PSTR + lane + 64 * i] = a.x + a.y;             // consecutive lanes, consecutive words: conflict-free
     }
   };
 
@@ -251,13 +248,17 @@ __global__ __launch_bounds__(NT) void k_gru_fwd2(const float* __restrict__ gi, c
   auto phase2 = [&](int s, float (&gin)[3]) {
     const int cur = s & 1;
     const int t = d ? T - 1 - s : s;
-    float s0 = bh0, s1 = bh1, s2 = bh2;
+    float p0[KC], p1[KC], p2[KC];
 #pragma unroll
-    for (int k = 0; k < KC; ++k) {       // fixed order: bitwise reproducible
-      s0 += part[k * PSTR + u];
-      s1 += part[k * PSTR + HH + u];
-      s2 += part[k * PSTR + 2 * HH + u];
+    for (int k = 0; k < KC; ++k) {
+      p0[k] = part[k * PSTR + u];
+      p1[k] = part[k * PSTR + HH + u];
+      p2[k] = part[k * PSTR + 2 * HH + u];
     }
+    // fixed-shape tree (depth 3 instead of a chain of 8 dependent adds; same order every run: bitwise reproducible)
+    const float s0 = (((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p0[4] + p0[5]) + (p0[6] + p0[7]))) + bh0;
+    const float s1 = (((p1[0] + p1[1]) + (p1[2] + p1[3])) + ((p1[4] + p1[5]) + (p1[6] + p1[7]))) + bh1;
+    const float s2 = (((p2[0] + p2[1]) + (p2[2] + p2[3])) + ((p2[4] + p2[5]) + (p2[6] + p2[7]))) + bh2;
     const float rr = sigmoidf_(gin[0] + s0);
     const float zz = sigmoidf_(gin[1] + s1);
     const float nn = tanhf_(gin[2] + rr * s2);
@@ -377,18 +378,20 @@ __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, co
 // ---- two-phase backward (same split as k_gru_fwd2) ------------------------------------------------------------------
 //   phase A (waves 0 and 1, one lane per hidden unit): carry = dh_{t+1} z_{t+1} + the 8 partial sums of W_hh^T dgh left
 //            by phase B of the previous step; gate gradients; dgi / dhn to HBM; the three dgh vectors to LDS;
-//   phase B (all 8 waves): 48 packed FMAs of the lane's 48-row chunk of W_hh^T, partial sums to LDS.
+//   phase B (all 8 waves; wave = 48 rows of W_hh, lane = two hidden units): the wave's 48 dgh values from LDS (one
+//            address for all lanes), 48 packed FMAs, two partial sums to LDS.
 __global__ __launch_bounds__(NT) void k_gru_bwd2(const float* __restrict__ dy, const float* __restrict__ y,
                                                  const float* __restrict__ saved, const float* __restrict__ w_hh,
                                                  int T, float* __restrict__ dgi, float* __restrict__ dhn_out) {
   __shared__ __attribute__((aligned(16))) float dgh[3 * HH];
-  __shared__ __attribute__((aligned(16))) float cpart[KC * (HH + 16)];
-  constexpr int CSTR = HH + 16;
+  __shared__ __attribute__((aligned(16))) float cpart[KC * HH];
+  constexpr int CSTR = HH;
   const int b = blockIdx.x >> 1, d = blockIdx.x & 1;
-  const int tid = threadIdx.x, g = tid >> 3, kc = tid & 7;
-  const int u0 = 2 * g;
+  const int tid = threadIdx.x;
+  const int kc = __builtin_amdgcn_readfirstlane(tid >> 6);       // this WAVE's chunk of 48 rows j of W_hh: dgh[j] is wave-uniform
+  const int u0 = 2 * (tid & 63);                                 // lane -> hidden units u0, u0 + 1
   const float* W = w_hh + static_cast<size_t>(d) * 3 * HH * HH;
-  constexpr int JC = 3 * HH / KC;   // 48 rows of W per lane chunk
+  constexpr int JC = 3 * HH / KC;   // 48 rows of W per wave
   f32x2 wa[JC / 2], wb[JC / 2];     // unit u0 / u0+1: (W[j][u], W[j+1][u]) pairs over the chunk's rows
 #pragma unroll
   for (int j = 0; j < JC; j += 2) {
@@ -444,9 +447,10 @@ __global__ __launch_bounds__(NT) void k_gru_bwd2(const float* __restrict__ dy, c
   float dhz = 0.f;
   auto phaseA = [&](int s, StepIn& in) {
     const int t = d ? s : T - 1 - s;
-    float carry = dhz;
+    float cp[KC];
 #pragma unroll
-    for (int k = 0; k < KC; ++k) carry += cpart[k * CSTR + u];          // fixed order
+    for (int k = 0; k < KC; ++k) cp[k] = cpart[k * CSTR + u];
+    const float carry = (((cp[0] + cp[1]) + (cp[2] + cp[3])) + ((cp[4] + cp[5]) + (cp[6] + cp[7]))) + dhz;   // fixed-shape tree
     const float dh = in.dyv + carry;
     const float dn = dh * (1.f - in.z);
     const float dz = dh * (in.hp - in.n);
