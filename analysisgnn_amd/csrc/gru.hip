@@ -5,39 +5,20 @@
 // The library RNN path launches several tiny kernels per time step (T = 500 steps x 2 layers):
 // ~24 000 launches per training step, >90 % of the step.  Here one 512-thread workgroup owns one
 // (sequence, direction) chain for ALL T steps: W_hh (3*HH x HH fp32 = 192 KiB at HH = 128) lives in
-// registers (96 per thread), h_{t-1} in LDS (double-buffered, one barrier per step), the
-// recurrent mat-vec is 96 FMAs per thread + a 3-step DPP butterfly over the 8 lanes that share
-// an output row.  The input projection x W_ih^T (+b_ih) is a plain library GEMM done beforehand
-// for all steps at once.  The backward kernel walks the chain in reverse with W_hh^T in
-// registers and emits dGI / dHN; weight gradients are library GEMMs over those.
+// registers (96 per thread), h_{t-1} in LDS.  The input projection x W_ih^T (+b_ih) is a plain library
+// GEMM done beforehand for all steps at once; the backward kernel walks the chain in reverse with
+// W_hh^T in registers and emits dGI / dHN, weight gradients are GEMMs over those (gru.py).
+// A time step is two phases with an LDS-only barrier after each (see the kernels).
 // fp32 throughout (v_exp/v_rcp gate functions, ~3 ulp), no atomics, bitwise reproducible run to run.
-#include <cstdlib>
-
 #include "agnn_common.h"
 
 namespace {
 
 constexpr int HH = 128;        // hidden size per direction
-constexpr int NT = 512;        // threads per chain: 64 unit-pairs x 8 k-chunks
+constexpr int NT = 512;        // threads per chain: 8 waves = 8 chunks of the reduction dimension
 constexpr int KC = 8;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float dpp_xor1(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
-}
-__device__ __forceinline__ float dpp_xor2(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
-}
-__device__ __forceinline__ float dpp_half_mirror(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false)); // lane i <-> 7-i in each 8
-}
-// sum over the 8 consecutive lanes of a unit-pair group; every lane ends with the total
-__device__ __forceinline__ float group8_sum(float v) {
-  v += dpp_xor1(v);
-  v += dpp_xor2(v);
-  v += dpp_half_mirror(v);
-  return v;
-}
 // Workgroup barrier that orders LDS traffic only.  `__syncthreads()` also waits for every outstanding
 // global load/store (s_waitcnt vmcnt(0)), which would put one HBM store round trip and the prefetch of
 // the next step's inputs on the critical path of EVERY time step of the recurrence.
@@ -53,135 +34,22 @@ __device__ __forceinline__ float tanhf_(float x) { return 2.f * __builtin_amdgcn
 // w_hh [2, 3*HH, HH], b_hh [2, 3*HH]
 // y    [B, T, 2*HH]
 // saved[B, T, 2, 4, HH]  = r, z, n, (W_hn h + b_hn)
-__global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, const float* __restrict__ w_hh,
-                                                const float* __restrict__ b_hh, int T, float* __restrict__ y,
-                                                float* __restrict__ saved) {
-  __shared__ __attribute__((aligned(16))) float hbuf[2][HH + NT];       // [HH, HH + NT): dummy slots
-  const int b = blockIdx.x >> 1, d = blockIdx.x & 1;
-  const int tid = threadIdx.x, g = tid >> 3, kc = tid & 7;
-  const int u0 = 2 * g;
-  const float* W = w_hh + static_cast<size_t>(d) * 3 * HH * HH;
-  float w[3][2][16];
-#pragma unroll
-  for (int gate = 0; gate < 3; ++gate)
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const float4* src = reinterpret_cast<const float4*>(W + static_cast<size_t>(gate * HH + u0 + q) * HH + 16 * kc);
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const float4 t4 = src[v];
-        w[gate][q][4 * v + 0] = t4.x; w[gate][q][4 * v + 1] = t4.y;
-        w[gate][q][4 * v + 2] = t4.z; w[gate][q][4 * v + 3] = t4.w;
-      }
-    }
-  float bh[3][2];
-#pragma unroll
-  for (int gate = 0; gate < 3; ++gate)
-#pragma unroll
-    for (int q = 0; q < 2; ++q) bh[gate][q] = kc == 0 ? b_hh[d * 3 * HH + gate * HH + u0 + q] : 0.f;
-  if (tid < HH) { hbuf[0][tid] = 0.f; hbuf[1][tid] = 0.f; }
-  float hprev[2] = {0.f, 0.f};
-  __syncthreads();
-
-  const size_t row3 = static_cast<size_t>(2) * 3 * HH;
-  // The loop body is branch-free on purpose.  With an `if (kc == 0)` around the stores the compiler lost count of the
-  // outstanding memory operations at the join and waited for ALL of them (s_waitcnt vmcnt(0)) in every step, i.e.
-  // for the input-projection load issued a few hundred cycles earlier: each step cost one full memory round trip
-  // (0.87 us).  Now every lane issues exactly one global store per step (lane kc of a unit-pair group stores
-  // h / r / z / n / W_hn h; lanes 5-7 repeat lane 4's store), all lanes write the same h to LDS, and the input
-  // projections are fetched FOUR steps ahead into a register ring (clamped index instead of a guard).
-  auto load_gi = [&](int s_, float (&g3)[3][2]) {
-    const int sc = s_ < T ? s_ : T - 1;
-    const int t_ = d ? T - 1 - sc : sc;
-    const float* p = gi + (static_cast<size_t>(b) * T + t_) * row3 + static_cast<size_t>(d) * 3 * HH + u0;
-#pragma unroll
-    for (int gate = 0; gate < 3; ++gate) {
-      const float2 v = *reinterpret_cast<const float2*>(p + gate * HH);
-      g3[gate][0] = v.x; g3[gate][1] = v.y;
-    }
-  };
-  const int h_slot = kc < 2 ? u0 + kc : HH + tid;
-  const int ks = kc < 4 ? kc : 4;                         // which of the 5 per-step outputs this lane stores
-  float* const st_base = ks == 0 ? y + d * HH + u0 : saved + static_cast<size_t>(d) * 4 * HH + static_cast<size_t>(ks - 1) * HH + u0;
-  const size_t st_stride = ks == 0 ? static_cast<size_t>(2) * HH : static_cast<size_t>(2) * 4 * HH;
-  auto step = [&](int s, float (&gin)[3][2]) {
-    const int cur = s & 1;
-    const int t = d ? T - 1 - s : s;
-    float hk[16];
-    {
-      const float4* hp = reinterpret_cast<const float4*>(&hbuf[cur][16 * kc]);
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const float4 t4 = hp[v];
-        hk[4 * v + 0] = t4.x; hk[4 * v + 1] = t4.y; hk[4 * v + 2] = t4.z; hk[4 * v + 3] = t4.w;
-      }
-    }
-    float gh[3][2];
-#pragma unroll
-    for (int gate = 0; gate < 3; ++gate)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        // packed fp32 FMA (v_pk_fma_f32): even / odd k in the two halves; the bias rides in lane kc == 0's accumulator
-        f32x2 acc = {bh[gate][q], 0.f};
-#pragma unroll
-        for (int k = 0; k < 16; k += 2) {
-          const f32x2 wv = {w[gate][q][k], w[gate][q][k + 1]};
-          const f32x2 hv = {hk[k], hk[k + 1]};
-          acc = __builtin_elementwise_fma(wv, hv, acc);
-        }
-        gh[gate][q] = group8_sum(acc.x + acc.y);
-      }
-    float hnew[2], rr[2], zz[2], nn[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      rr[q] = sigmoidf_(gin[0][q] + gh[0][q]);
-      zz[q] = sigmoidf_(gin[1][q] + gh[1][q]);
-      nn[q] = tanhf_(gin[2][q] + rr[q] * gh[2][q]);
-      hnew[q] = (1.f - zz[q]) * nn[q] + zz[q] * hprev[q];
-      hprev[q] = hnew[q];
-    }
-    // lanes kc = 0 / 1 write the pair's two h values, the others a private dummy slot: no exec-mask branch and no
-    // same-address write conflict (LDS serialises lanes that WRITE one address)
-    hbuf[cur ^ 1][h_slot] = kc == 1 ? hnew[1] : hnew[0];
-    float2 sv2;
-    sv2.x = ks == 0 ? hnew[0] : (ks == 1 ? rr[0] : (ks == 2 ? zz[0] : (ks == 3 ? nn[0] : gh[2][0])));
-    sv2.y = ks == 0 ? hnew[1] : (ks == 1 ? rr[1] : (ks == 2 ? zz[1] : (ks == 3 ? nn[1] : gh[2][1])));
-    *reinterpret_cast<float2*>(st_base + (static_cast<size_t>(b) * T + t) * st_stride) = sv2;
-    load_gi(s + 4, gin);                                    // refill this ring slot
-    lds_barrier();
-  };
-  float g0[3][2], g1[3][2], g2[3][2], g3[3][2];
-  load_gi(0, g0);
-  load_gi(1, g1);
-  load_gi(2, g2);
-  load_gi(3, g3);
-  int s = 0;
-  for (; s + 4 <= T; s += 4) {
-    step(s, g0);
-    step(s + 1, g1);
-    step(s + 2, g2);
-    step(s + 3, g3);
-  }
-  if (s < T) step(s, g0);
-  if (s + 1 < T) step(s + 1, g1);
-  if (s + 2 < T) step(s + 2, g2);
-}
-
-// ---- two-phase forward -------------------------------------------------------------------------------------------
-// The kernel above is bound by instruction issue: every one of the 8 waves runs the whole step body (~250 instructions),
-// of which only 48 packed FMAs are the mat-vec — the gate math, address arithmetic, loads and stores are repeated by all
-// 8 lanes that share a unit pair.  Here a step has two phases:
+// ---- forward ---------------------------------------------------------------------------------------------------------
+// A one-phase version (every lane: mat-vec slice, 3-step DPP butterfly, gates, stores) was bound by instruction issue:
+// ~250 instructions per wave per step, of which 48 packed FMAs are the mat-vec — the gate math, address arithmetic, loads
+// and stores were repeated by all 8 lanes sharing a unit pair (0.78 us per step).  Now (0.61 us per step):
 //   phase 1 (all 8 waves; wave = one 16-wide k chunk of W_hh, lane = six of its 384 rows): the wave's h chunk from LDS
 //            (one address for all lanes), 48 packed FMAs, six partial sums to LDS (part[kc][gate][unit], no cross-lane
 //            reduction at all);
 //   phase 2 (waves 0 and 1, one lane per hidden unit): add the 8 partials per gate in a fixed order, gates, h_t to LDS,
 //            the five per-step outputs to HBM (coalesced over units), prefetch of the input projections 4 steps ahead.
-// Two LDS-only barriers per step; waves 2-7 run a loop that contains phase 1 only (so the loop of the unit-lane waves is
-// straight-line code with unconditional loads / stores and counted s_waitcnt).  ~75 + ~90/4 instruction slots per
-// SIMD-wave pair instead of 2 x 250.
+// Waves 2-7 run a loop that contains phase 1 only, so the loop of the unit-lane waves is straight-line code with
+// unconditional loads / stores and counted s_waitcnt (a branch around a memory operation makes the compiler wait for
+// ALL outstanding operations at the join, which put one memory round trip into every step).
+// Tried, slower: two EXTRA waves for phase 2 (640 threads) with their stores deferred behind the second barrier.
 constexpr int PSTR = 3 * HH;           // part[kc][gate*HH + unit]
 
-__global__ __launch_bounds__(NT) void k_gru_fwd2(const float* __restrict__ gi, const float* __restrict__ w_hh,
+__global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, const float* __restrict__ w_hh,
                                                  const float* __restrict__ b_hh, int T, float* __restrict__ y,
                                                  float* __restrict__ saved) {
   __shared__ __attribute__((aligned(16))) float hbuf[2][HH];
@@ -293,94 +161,12 @@ __global__ __launch_bounds__(NT) void k_gru_fwd2(const float* __restrict__ gi, c
 
 // dy [B,T,2*HH]; y, saved from the forward; outputs dgi [B,T,2,3*HH] (d r_pre, d z_pre, d n_pre) and
 // dhn [B,T,2,HH] (gradient of W_hn h + b_hn).
-__global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, const float* __restrict__ y,
-                                                const float* __restrict__ saved, const float* __restrict__ w_hh,
-                                                int T, float* __restrict__ dgi, float* __restrict__ dhn_out) {
-  __shared__ __attribute__((aligned(16))) float dgh[2][3 * HH];
-  const int b = blockIdx.x >> 1, d = blockIdx.x & 1;
-  const int tid = threadIdx.x, g = tid >> 3, kc = tid & 7;
-  const int u0 = 2 * g;
-  const float* W = w_hh + static_cast<size_t>(d) * 3 * HH * HH;
-  constexpr int JC = 3 * HH / KC;   // 48 rows of W per lane chunk
-  float wt[2][JC];
-#pragma unroll
-  for (int j = 0; j < JC; ++j) {
-    const float2 v = *reinterpret_cast<const float2*>(W + static_cast<size_t>(JC * kc + j) * HH + u0);
-    wt[0][j] = v.x; wt[1][j] = v.y;
-  }
-  float carry[2] = {0.f, 0.f};
-  // per-step operands (dy, saved gates, h_{t-1}) are fetched one step ahead
-  struct StepIn { float2 dyv, r2, z2, n2, q2, hp2; };
-  auto fetch = [&](int s_) {
-    StepIn o;
-    const int t_ = d ? s_ : T - 1 - s_;
-    const int tp_ = d ? t_ + 1 : t_ - 1;
-    const size_t bt_ = static_cast<size_t>(b) * T + t_;
-    o.dyv = *reinterpret_cast<const float2*>(dy + bt_ * 2 * HH + d * HH + u0);
-    const float* sv = saved + (bt_ * 2 + d) * 4 * HH + u0;
-    o.r2 = *reinterpret_cast<const float2*>(sv + 0 * HH);
-    o.z2 = *reinterpret_cast<const float2*>(sv + 1 * HH);
-    o.n2 = *reinterpret_cast<const float2*>(sv + 2 * HH);
-    o.q2 = *reinterpret_cast<const float2*>(sv + 3 * HH);
-    o.hp2 = make_float2(0.f, 0.f);
-    if (tp_ >= 0 && tp_ < T) o.hp2 = *reinterpret_cast<const float2*>(y + (static_cast<size_t>(b) * T + tp_) * 2 * HH + d * HH + u0);
-    return o;
-  };
-  StepIn nxt = fetch(0);
-  for (int s = 0; s < T; ++s) {
-    const int cur = s & 1;
-    const int t = d ? s : T - 1 - s;            // reverse of the forward walk
-    const size_t bt = static_cast<size_t>(b) * T + t;
-    const StepIn in = nxt;
-    if (s + 1 < T) nxt = fetch(s + 1);
-    const float dyq[2] = {in.dyv.x, in.dyv.y}, r[2] = {in.r2.x, in.r2.y}, z[2] = {in.z2.x, in.z2.y},
-                n[2] = {in.n2.x, in.n2.y}, hn[2] = {in.q2.x, in.q2.y}, hp[2] = {in.hp2.x, in.hp2.y};
-    float dh[2], drp[2], dzp[2], dnp[2], dq[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      dh[q] = dyq[q] + carry[q];
-      const float dn = dh[q] * (1.f - z[q]);
-      const float dz = dh[q] * (hp[q] - n[q]);
-      dnp[q] = dn * (1.f - n[q] * n[q]);
-      const float dr = dnp[q] * hn[q];
-      dq[q] = dnp[q] * r[q];
-      dzp[q] = dz * z[q] * (1.f - z[q]);
-      drp[q] = dr * r[q] * (1.f - r[q]);
-    }
-    if (kc == 0) {
-      float* go = dgi + (bt * 2 + d) * 3 * HH + u0;
-      *reinterpret_cast<float2*>(go + 0 * HH) = make_float2(drp[0], drp[1]);
-      *reinterpret_cast<float2*>(go + 1 * HH) = make_float2(dzp[0], dzp[1]);
-      *reinterpret_cast<float2*>(go + 2 * HH) = make_float2(dnp[0], dnp[1]);
-      *reinterpret_cast<float2*>(dhn_out + (bt * 2 + d) * HH + u0) = make_float2(dq[0], dq[1]);
-      *reinterpret_cast<float2*>(&dgh[cur][0 * HH + u0]) = make_float2(drp[0], drp[1]);
-      *reinterpret_cast<float2*>(&dgh[cur][1 * HH + u0]) = make_float2(dzp[0], dzp[1]);
-      *reinterpret_cast<float2*>(&dgh[cur][2 * HH + u0]) = make_float2(dq[0], dq[1]);
-    }
-    lds_barrier();
-    // packed fp32 FMA (v_pk_fma_f32): even / odd rows j of W^T in the two halves of each accumulator
-    f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
-    const float4* gp = reinterpret_cast<const float4*>(&dgh[cur][JC * kc]);
-#pragma unroll
-    for (int v = 0; v < JC / 4; ++v) {
-      const float4 t4 = gp[v];
-      const f32x2 lo = {t4.x, t4.y}, hi = {t4.z, t4.w};
-      a0 = __builtin_elementwise_fma(f32x2{wt[0][4 * v + 0], wt[0][4 * v + 1]}, lo, a0);
-      a1 = __builtin_elementwise_fma(f32x2{wt[1][4 * v + 0], wt[1][4 * v + 1]}, lo, a1);
-      a0 = __builtin_elementwise_fma(f32x2{wt[0][4 * v + 2], wt[0][4 * v + 3]}, hi, a0);
-      a1 = __builtin_elementwise_fma(f32x2{wt[1][4 * v + 2], wt[1][4 * v + 3]}, hi, a1);
-    }
-    carry[0] = dh[0] * z[0] + group8_sum(a0.x + a0.y);
-    carry[1] = dh[1] * z[1] + group8_sum(a1.x + a1.y);
-  }
-}
-
-// ---- two-phase backward (same split as k_gru_fwd2) ------------------------------------------------------------------
+// ---- two-phase backward (same split as k_gru_fwd) ------------------------------------------------------------------
 //   phase A (waves 0 and 1, one lane per hidden unit): carry = dh_{t+1} z_{t+1} + the 8 partial sums of W_hh^T dgh left
 //            by phase B of the previous step; gate gradients; dgi / dhn to HBM; the three dgh vectors to LDS;
 //   phase B (all 8 waves; wave = 48 rows of W_hh, lane = two hidden units): the wave's 48 dgh values from LDS (one
 //            address for all lanes), 48 packed FMAs, two partial sums to LDS.
-__global__ __launch_bounds__(NT) void k_gru_bwd2(const float* __restrict__ dy, const float* __restrict__ y,
+__global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, const float* __restrict__ y,
                                                  const float* __restrict__ saved, const float* __restrict__ w_hh,
                                                  int T, float* __restrict__ dgi, float* __restrict__ dhn_out) {
   __shared__ __attribute__((aligned(16))) float dgh[3 * HH];
@@ -492,12 +278,7 @@ extern "C" int agnn_gru_fwd_f32(const float* gi, const float* w_hh, const float*
   if (B == 0 || T == 0) return AGNN_OK;
   if (!gi || !w_hh || !b_hh || !y || !saved) return fail(AGNN_EINVAL, "gru_fwd: null argument");
   if (!aligned16(gi) || !aligned16(w_hh) || !aligned16(y) || !aligned16(saved)) return fail(AGNN_EALIGN, "gru_fwd: pointers must be 16-byte aligned");
-  static const bool v1 = getenv("AGNN_GRU_V1") != nullptr;          // A/B: the one-phase kernel
-  if (v1)
-    hipLaunchKernelGGL(k_gru_fwd, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), gi,
-                       w_hh, b_hh, static_cast<int>(T), y, saved);
-  else
-    hipLaunchKernelGGL(k_gru_fwd2, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), gi,
+  hipLaunchKernelGGL(k_gru_fwd, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), gi,
                        w_hh, b_hh, static_cast<int>(T), y, saved);
   return check_launch("gru_fwd");
 }
@@ -510,12 +291,7 @@ extern "C" int agnn_gru_bwd_f32(const float* dy, const float* y, const float* sa
   if (B == 0 || T == 0) return AGNN_OK;
   if (!dy || !y || !saved || !w_hh || !dgi || !dhn) return fail(AGNN_EINVAL, "gru_bwd: null argument");
   if (!aligned16(dy) || !aligned16(y) || !aligned16(saved) || !aligned16(w_hh) || !aligned16(dgi) || !aligned16(dhn)) return fail(AGNN_EALIGN, "gru_bwd: pointers must be 16-byte aligned");
-  static const bool v1 = getenv("AGNN_GRU_V1") != nullptr;          // A/B: the one-phase kernel
-  if (v1)
-    hipLaunchKernelGGL(k_gru_bwd, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), dy, y,
-                       saved, w_hh, static_cast<int>(T), dgi, dhn);
-  else
-    hipLaunchKernelGGL(k_gru_bwd2, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), dy, y,
+  hipLaunchKernelGGL(k_gru_bwd, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), dy, y,
                        saved, w_hh, static_cast<int>(T), dgi, dhn);
   return check_launch("gru_bwd");
 }
