@@ -145,7 +145,7 @@ class HeteroConv(nn.Module):
             convs = [self.convs[et_key(et)] for et in ets]
             W_l, b, W_r = sage_operands([c.lin_l.weight for c in convs], [c.lin_l.bias for c in convs],
                                         [c.lin_r.weight for c in convs])                 # [out, R*H], [out], [out, H]
-            y = linear(x_dict[d][:n], W_r, None, acc=linear(A, W_l, b))                   # second GEMM accumulates (beta = 1)
+            y = linear(_head(x_dict[d], n), W_r, None, acc=linear(A, W_l, b))                   # second GEMM accumulates (beta = 1)
             out[d] = y / len(ets) if self.aggr == "mean" else y
         return out
 
@@ -199,6 +199,12 @@ def _sequence_lengths(batch: torch.Tensor):
     return hit[0], hit[1]
 
 
+def _head(t: torch.Tensor, n: int) -> torch.Tensor:
+    """t[:n] without an autograd node when it is the whole tensor (SliceBackward costs a zero-fill, a copy and, for a
+    tensor with a second consumer, a gradient add per use)."""
+    return t if n >= t.shape[0] else t[:n]
+
+
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -246,18 +252,18 @@ class _HybridMixin:
         else:
             batch_note = batch_dict["note"][:batch_size]
         if not (self.overlap_sequence_branch and x_in.is_cuda):
-            return self.hybrid_forward(x_in[:batch_size], batch_note), None
+            return self.hybrid_forward(_head(x_in, batch_size), batch_note), None
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            z = self.hybrid_forward(x_in[:batch_size], batch_note)
+            z = self.hybrid_forward(_head(x_in, batch_size), batch_note)
         return z, side
 
     def _finish(self, x_note, outs, z, side, batch_size):
-        x = x_note[:batch_size]
+        x = _head(x_note, batch_size)
         if self.use_jk:
-            x = self.jk([o[:batch_size] for o in outs])
+            x = self.jk([_head(o, batch_size) for o in outs])
         if side is not None:
             torch.cuda.current_stream(x.device).wait_stream(side)
             z.record_stream(torch.cuda.current_stream(x.device))
@@ -318,8 +324,8 @@ class MetricalGNN(nn.Module):
         outs: list = []
         h = self.gnn(x_dict, edge_index_dict, plan, outs)["note"]
         if batch_size is not None:
-            h = h[:batch_size]
-            outs = [o[:batch_size] for o in outs]
+            h = _head(h, batch_size)
+            outs = [_head(o, batch_size) for o in outs]
         if self.use_jk:
             h = self.jk(outs)
         out = self.mlp(h)

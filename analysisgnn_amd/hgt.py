@@ -242,7 +242,7 @@ class HGTConv(nn.Module):
             o = self.out_lin.lins[t](F.gelu(m))
             if o.shape[-1] == x.shape[-1]:
                 beta = torch.sigmoid(self.skip[t])
-                o = beta * o + (1 - beta) * x[:n]
+                o = beta * o + (1 - beta) * (x if n >= x.shape[0] else x[:n])
             out[t] = o
         return out
 
