@@ -189,3 +189,53 @@ def test_spmm_c2_shape_against_oracle():
     lhs = float((out.detach().double() * gout.double()).sum())
     rhs = float((xd.detach().double() * xd.grad.double()).sum())
     assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs))
+
+
+def test_pack_items_sum_and_strided_pieces():
+    """agnn_pack_f32 through analysisgnn_amd.params.pack: strided destinations, several sources, odd sizes, > 24 items."""
+    from analysisgnn_amd.params import pack
+    torch.manual_seed(0)
+    dev = "cuda:0"
+    big = torch.zeros(37, 4 * 20 + 3, device=dev)
+    srcs = [torch.randn(37, 20, device=dev) for _ in range(4)]
+    items = [(big[:, 20 * r:20 * (r + 1)], [srcs[r]]) for r in range(4)]            # cat along columns (ld_dst > cols)
+    acc = torch.empty(37, 20, device=dev)
+    items.append((acc, srcs))                                                        # sum of four
+    vec = torch.empty(1, 131, device=dev)
+    vs = [torch.randn(1, 131, device=dev) for _ in range(3)]
+    items.append((vec, vs))                                                          # odd width: scalar path
+    many_dst = [torch.empty(5, 8, device=dev) for _ in range(30)]
+    many_src = [torch.randn(5, 8, device=dev) for _ in range(30)]
+    items += [(d, [s]) for d, s in zip(many_dst, many_src)]                          # more than one launch worth of items
+    pack(items, torch.device(dev))
+    torch.cuda.synchronize()
+    assert torch.equal(big[:, :80], torch.cat(srcs, dim=1)) and float(big[:, 80:].abs().max()) == 0.0
+    assert torch.allclose(acc, srcs[0] + srcs[1] + srcs[2] + srcs[3], rtol=0, atol=1e-6)
+    assert torch.allclose(vec, vs[0] + vs[1] + vs[2], rtol=0, atol=1e-6)
+    assert all(torch.equal(d, s) for d, s in zip(many_dst, many_src))
+
+
+def test_multitask_ce_uncovered_columns_and_ignored_rows():
+    """Segments that do not cover every column (zero-filled gradient there), all-ignored task, C > 192 (strided path)."""
+    from analysisgnn_amd.heads import multitask_cross_entropy
+    import torch.nn.functional as F
+    torch.manual_seed(1)
+    dev = "cuda:0"
+    N = 203
+    offs = [2, 7, 7 + 200, 7 + 200 + 3]                   # columns 0-1 and the tail belong to no task
+    width = offs[-1] + 4
+    logits = torch.randn(N, width, device=dev, requires_grad=True)
+    labels = torch.stack([torch.randint(0, 5, (N,)), torch.randint(0, 200, (N,)), torch.full((N,), -1)]).to(dev)
+    labels[0, ::3] = -1
+    loss = multitask_cross_entropy(logits, offs, labels, 0.1, -1)
+    (loss * torch.tensor([1.0, 2.0, 3.0], device=dev)).sum().backward()
+    ref_in = logits.detach().double().cpu().requires_grad_(True)
+    ref = []
+    for t in range(3):
+        seg = ref_in[:, offs[t]:offs[t + 1]]
+        lab = labels[t].cpu()
+        ref.append(F.cross_entropy(seg, lab, ignore_index=-1, label_smoothing=0.1) if (lab != -1).any() else seg.sum() * 0.0)
+    ref = torch.stack(ref)
+    (ref * torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64)).sum().backward()
+    assert torch.allclose(loss.cpu().double(), ref.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(logits.grad.cpu().double(), ref_in.grad, rtol=1e-4, atol=1e-7)
