@@ -17,6 +17,7 @@ from . import _lib
 from .encoders import TrimPlan, _HybridMixin
 from .graph import Csr, HeteroIndex, hetero_index
 from .linear import linear
+from .params import pack
 
 EdgeType = Tuple[str, str, str]
 
@@ -136,6 +137,40 @@ class _HGTAttention(torch.autograd.Function):
         return (None, dq, dps, *grads)
 
 
+class _ColSplit(torch.autograd.Function):
+    """G column blocks of a [N, G*H] matrix as views (row stride G*H, no copies).  Plain slicing would make autograd
+    materialise one zero-filled [N, G*H] gradient per block and add them up; here the backward gathers the blocks'
+    gradients into one [N, G*H] buffer with a single `agnn_pack_f32` launch."""
+
+    @staticmethod
+    def forward(ctx, big, G: int):
+        N, W = big.shape
+        ctx.meta = (N, W, G)
+        H = W // G
+        return tuple(big[:, g * H:(g + 1) * H] for g in range(G))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        N, W, G = ctx.meta
+        H = W // G
+        ref = next(g for g in grads if g is not None)
+        dbig = torch.empty((N, W), dtype=torch.float32, device=ref.device)
+        items = []
+        for g_i, g in enumerate(grads):
+            blk = dbig[:, g_i * H:(g_i + 1) * H]
+            if g is None:
+                blk.zero_()
+            elif N > 0:
+                items.append((blk, [_mat(g)]))
+        if items:
+            pack(items, ref.device)
+        return dbig, None
+
+
+def col_split(big: torch.Tensor, G: int):
+    return _ColSplit.apply(big, G)
+
+
 class _DictLinear(nn.Module):
     """`HeteroDictLinear`: one Linear per node type, parameters under `lins.<type>`."""
 
@@ -190,15 +225,12 @@ class HGTConv(nn.Module):
         heads, H = self.heads, self.out_channels
         D = H // heads
         n_of = {t: (n_keep[t] if n_keep is not None else int(x.shape[0])) for t, x in x_dict.items()}
-        # k, q, v as three projections with row-slices of the fused kqv weight: slicing a [3H, in] weight is free, while
-        # slicing the [N, 3H] activation makes autograd materialise three zero-filled [N, 3H] gradients and add them
+        # k | q | v in ONE projection per node type; the three H-wide column blocks are handed out as views (col_split)
         k, q, v = {}, {}, {}
         for t, x in x_dict.items():
             lin = self.kqv_lin.lins[t]
-            xt = x[:n_of[t]]
-            k[t] = linear(xt, lin.weight[:H], lin.bias[:H])
-            q[t] = linear(xt, lin.weight[H:2 * H], lin.bias[H:2 * H])
-            v[t] = linear(xt, lin.weight[2 * H:], lin.bias[2 * H:])
+            xt = x if n_of[t] >= x.shape[0] else x[:n_of[t]]
+            k[t], q[t], v[t] = col_split(linear(xt, lin.weight, lin.bias), 3)
         by_dst: Dict[str, List[Tuple[int, EdgeType]]] = {}
         for e_idx, et in enumerate(self.edge_types):
             s, _, d = et
@@ -220,9 +252,19 @@ class HGTConv(nn.Module):
                 wb[:, ar, :, ar, :] = w4.permute(1, 0, 2, 3)                                # block (h, h) of relation r
                 return wb.view(len(used), H, H)
             Wk, Wv = dense(self.k_rel.weight), dense(self.v_rel.weight)
+            # all relations leaving one source type share their input: ONE GEMM [N_s, H] x [H, R_s*H] for the keys and one
+            # for the values (weight gradient [R_s*H, H] in one piece), the relations' blocks handed out as column views
+            by_src: Dict[str, List[int]] = {}
             for i, e_idx in enumerate(used):
-                s_t = self.edge_types[e_idx][0]
-                kv_of[e_idx] = (linear(k[s_t], Wk[i].t()), linear(v[s_t], Wv[i].t()))
+                by_src.setdefault(self.edge_types[e_idx][0], []).append(i)
+            for s_t, pos in by_src.items():
+                sel_s = _index_tensor(tuple(pos), dev)
+                Wk_s = Wk.index_select(0, sel_s).transpose(1, 2).reshape(len(pos) * H, H)      # rows r*H..: (k A_r)^T layout for x W^T
+                Wv_s = Wv.index_select(0, sel_s).transpose(1, 2).reshape(len(pos) * H, H)
+                ks = col_split(linear(k[s_t], Wk_s), len(pos))
+                vs = col_split(linear(v[s_t], Wv_s), len(pos))
+                for j, i in enumerate(pos):
+                    kv_of[used[i]] = (ks[j], vs[j])
         out = {}
         for t, x in x_dict.items():
             n = n_of[t]
