@@ -180,7 +180,7 @@ def main():
                 for _ in range(3):
                     fwd_bwd(); flat.all_reduce_mean(); update()
             torch.cuda.current_stream(dev).wait_stream(side)
-            torch.cuda.synchronize(dev)
+            dp.barrier_and_sync()                               # no collective in flight on any rank while capturing
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 loss_ref[0] = fwd_bwd()
