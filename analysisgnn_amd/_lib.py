@@ -100,8 +100,8 @@ SIGNATURES = {
                                  C.c_void_p]),
     "agnn_multitask_ce_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_float,
                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "agnn_multitask_ce_scale_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
-                                              C.c_int64, C.c_void_p]),
+    "agnn_multitask_ce_scale_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p,
+                                              C.c_void_p, C.c_int64, C.c_void_p]),
 }
 
 

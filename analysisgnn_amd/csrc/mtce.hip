@@ -133,19 +133,20 @@ __global__ __launch_bounds__(1024) void k_mtce_reduce(const float* __restrict__ 
   }
 }
 
-// out[n, c] = dz[n, c] * scale[task(c)] for the columns of the T segments (float4 over whole rows when aligned)
+// out[n, c] = dz[n, c] * scale[task(c)] for the columns of the T segments; columns outside every segment are copied
 __global__ __launch_bounds__(256) void k_mtce_scale(const float* __restrict__ dz, int64_t ld, const int32_t* __restrict__ off, int T,
-                                                    int64_t n_rows, const float* __restrict__ scale, float* __restrict__ out, int64_t ld_out) {
+                                                    int64_t n_rows, int total_cols, const float* __restrict__ scale,
+                                                    float* __restrict__ out, int64_t ld_out) {
   const int lane = threadIdx.x & 63;
   const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (row >= n_rows) return;
   const float* zr = dz + row * ld;
   float* orow = out + row * ld_out;
-  const int width = off[T];
+  const int lo = off[0], hi = off[T];
   int t = 0;
-  for (int c = lane; c < width; c += 64) {
-    while (c >= off[t + 1]) ++t;                      // columns ascend per lane: the task index only moves forward
-    orow[c] = c >= off[0] ? zr[c] * scale[t] : zr[c];
+  for (int c = lane; c < total_cols; c += 64) {
+    while (t + 1 < T && c >= off[t + 1]) ++t;        // columns ascend per lane: the task index only moves forward
+    orow[c] = (c >= lo && c < hi) ? zr[c] * scale[t] : zr[c];
   }
 }
 
@@ -169,12 +170,12 @@ extern "C" int agnn_multitask_ce_f32(const float* logits, int64_t ld, const int3
 }
 
 extern "C" int agnn_multitask_ce_scale_f32(const float* dlogits, int64_t ld, const int32_t* seg_off, int32_t n_tasks, int64_t n_rows,
-                                           const float* scale, float* out, int64_t ld_out, agnn_stream_t stream_) {
+                                           int32_t n_cols, const float* scale, float* out, int64_t ld_out, agnn_stream_t stream_) {
   using namespace agnn;
-  if (n_rows < 0 || n_tasks < 0) return fail(AGNN_EINVAL, "multitask_ce_scale: negative size");
+  if (n_rows < 0 || n_tasks < 0 || n_cols < 0 || n_cols > ld || n_cols > ld_out) return fail(AGNN_EINVAL, "multitask_ce_scale: bad size");
   if (n_rows == 0 || n_tasks == 0) return AGNN_OK;
   if (!dlogits || !seg_off || !scale || !out) return fail(AGNN_EINVAL, "multitask_ce_scale: null argument");
   hipLaunchKernelGGL(k_mtce_scale, dim3(static_cast<unsigned>((n_rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream_),
-                     dlogits, ld, seg_off, n_tasks, n_rows, scale, out, ld_out);
+                     dlogits, ld, seg_off, n_tasks, n_rows, n_cols, scale, out, ld_out);
   return check_launch("multitask_ce_scale");
 }

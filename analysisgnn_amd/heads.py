@@ -148,7 +148,8 @@ class _MultiTaskCE(torch.autograd.Function):
         out = torch.empty_like(dlogits)
         lib = _lib.load()
         _lib.check(lib.agnn_multitask_ce_scale_f32(dlogits.data_ptr(), dlogits.stride(0), offs_t.data_ptr(), T, dlogits.shape[0],
-                                                   scale.data_ptr(), out.data_ptr(), out.stride(0), _lib.stream_ptr(dev)),
+                                                   dlogits.shape[1], scale.data_ptr(), out.data_ptr(), out.stride(0),
+                                                   _lib.stream_ptr(dev)),
                    "agnn_multitask_ce_scale_f32")
         return out, None, None, None, None, None
 

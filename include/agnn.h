@@ -297,15 +297,16 @@ int agnn_gproj_bwd_f32(const float* dout, int64_t ld_dout, const float* a, int64
  *                                columns outside the segments untouched)
  *   loss      [n_tasks]          mean loss per task = sum_n row_loss[t][n] / max(count_t, 1)
  *   inv_count [n_tasks]          1 / max(count_t, 1), count_t = rows with label != ignore_index
- * agnn_multitask_ce_scale_f32: out[n, c] = dlogits[n, c] * scale[task(c)] — the backward pass with
- * scale[t] = inv_count[t] * (incoming gradient of loss[t]).
+ * agnn_multitask_ce_scale_f32: out[n, c] = dlogits[n, c] * scale[task(c)] for c < n_cols (columns outside every
+ * segment are copied) — the backward pass with scale[t] = inv_count[t] * (incoming gradient of loss[t]).
  * ------------------------------------------------------------------------------------------ */
 int agnn_multitask_ce_f32(const float* logits, int64_t ld, const int32_t* seg_off, int32_t n_tasks,
                           const int64_t* labels, int64_t n_rows, float label_smoothing,
                           int64_t ignore_index, float* row_loss, float* dlogits, float* loss, float* inv_count,
                           agnn_stream_t stream);
 int agnn_multitask_ce_scale_f32(const float* dlogits, int64_t ld, const int32_t* seg_off, int32_t n_tasks,
-                                int64_t n_rows, const float* scale, float* out, int64_t ld_out, agnn_stream_t stream);
+                                int64_t n_rows, int32_t n_cols, const float* scale, float* out, int64_t ld_out,
+                                agnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Global-norm gradient clipping + AdamW over flat fp32 buffers (ref optimizer: models/analysis.py:1380-1381
