@@ -149,8 +149,7 @@ __global__ __launch_bounds__(256) void k_gproj_dw(GpArgs p) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
   float bs = 0.f;
-  for (int base = r0; base < r1; base += 16) {
-    float avv[8], bvv[8][NT];
+  auto fetch = [&](int base, float (&avv)[8], float (&bvv)[8][NT]) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int n = base + 2 * u + kk;
@@ -160,11 +159,25 @@ __global__ __launch_bounds__(256) void k_gproj_dw(GpArgs p) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) bvv[u][t] = ap[nn * p.ld_a + t * 32];
     }
+  };
+  auto mma = [&](const float (&avv)[8], const float (&bvv)[8][NT]) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(avv[u], bvv[u][t], acc[t], 0, 0, 0);
       bs += avv[u];
+    }
+  };
+  // two register sets in rotation: the next 16 rows are in flight during the MFMAs of the current 16
+  if (r0 < r1) {
+    float a0[8], b0[8][NT], a1[8], b1[8][NT];
+    fetch(r0, a0, b0);
+    for (int base = r0; base < r1; base += 32) {
+      if (base + 16 < r1) fetch(base + 16, a1, b1);
+      mma(a0, b0);
+      if (base + 16 >= r1) break;
+      if (base + 32 < r1) fetch(base + 32, a0, b0);
+      mma(a1, b1);
     }
   }
   float* slab = p.slab + (static_cast<int64_t>(slice) * p.sum_c + off) * K;
