@@ -160,15 +160,16 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
 }
 
 // dy [B,T,2*HH]; y, saved from the forward; outputs dgi [B,T,2,3*HH] (d r_pre, d z_pre, d n_pre) and
-// dhn [B,T,2,HH] (gradient of W_hn h + b_hn).
+// dgh [B,T,2,3*HH] (gradient w.r.t. W_h h + b_h: the r and z blocks of dgi again, and d n_pre * r in the n block —
+// written by the kernel so that the weight-gradient GEMM for W_hh needs no 49 MB concatenation).
 // ---- two-phase backward (same split as k_gru_fwd) ------------------------------------------------------------------
 //   phase A (waves 0 and 1, one lane per hidden unit): carry = dh_{t+1} z_{t+1} + the 8 partial sums of W_hh^T dgh left
-//            by phase B of the previous step; gate gradients; dgi / dhn to HBM; the three dgh vectors to LDS;
+//            by phase B of the previous step; gate gradients; dgi / dgh to HBM; the three dgh vectors to LDS;
 //   phase B (all 8 waves; wave = 48 rows of W_hh, lane = two hidden units): the wave's 48 dgh values from LDS (one
 //            address for all lanes), 48 packed FMAs, two partial sums to LDS.
 __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, const float* __restrict__ y,
                                                  const float* __restrict__ saved, const float* __restrict__ w_hh,
-                                                 int T, float* __restrict__ dgi, float* __restrict__ dhn_out) {
+                                                 int T, float* __restrict__ dgi, float* __restrict__ dgh_out) {
   __shared__ __attribute__((aligned(16))) float dgh[3 * HH];
   __shared__ __attribute__((aligned(16))) float cpart[KC * HH];
   constexpr int CSTR = HH;
@@ -254,7 +255,10 @@ __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, co
     go[0] = drp;
     go[HH] = dzp;
     go[2 * HH] = dnp;
-    dhn_out[(bt * 2 + d) * HH + u] = dq;
+    float* ho = dgh_out + (bt * 2 + d) * 3 * HH + u;
+    ho[0] = drp;
+    ho[HH] = dzp;
+    ho[2 * HH] = dq;
     fetch(s + 2, in);                    // refill this register set
   };
   StepIn inA, inB;
@@ -284,14 +288,14 @@ extern "C" int agnn_gru_fwd_f32(const float* gi, const float* w_hh, const float*
 }
 
 extern "C" int agnn_gru_bwd_f32(const float* dy, const float* y, const float* saved, const float* w_hh, int64_t B,
-                                int64_t T, int32_t hidden, float* dgi, float* dhn, agnn_stream_t stream_) {
+                                int64_t T, int32_t hidden, float* dgi, float* dgh, agnn_stream_t stream_) {
   using namespace agnn;
   if (hidden != HH) return fail(AGNN_EINVAL, "gru_bwd: hidden=%d unsupported (this build: %d)", hidden, HH);
   if (B < 0 || T < 0 || B * 2 >= (int64_t{1} << 31) || T >= (int64_t{1} << 31)) return fail(AGNN_EINVAL, "gru_bwd: bad B=%lld T=%lld", (long long)B, (long long)T);
   if (B == 0 || T == 0) return AGNN_OK;
-  if (!dy || !y || !saved || !w_hh || !dgi || !dhn) return fail(AGNN_EINVAL, "gru_bwd: null argument");
-  if (!aligned16(dy) || !aligned16(y) || !aligned16(saved) || !aligned16(w_hh) || !aligned16(dgi) || !aligned16(dhn)) return fail(AGNN_EALIGN, "gru_bwd: pointers must be 16-byte aligned");
+  if (!dy || !y || !saved || !w_hh || !dgi || !dgh) return fail(AGNN_EINVAL, "gru_bwd: null argument");
+  if (!aligned16(dy) || !aligned16(y) || !aligned16(saved) || !aligned16(w_hh) || !aligned16(dgi) || !aligned16(dgh)) return fail(AGNN_EALIGN, "gru_bwd: pointers must be 16-byte aligned");
   hipLaunchKernelGGL(k_gru_bwd, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), dy, y,
-                       saved, w_hh, static_cast<int>(T), dgi, dhn);
+                       saved, w_hh, static_cast<int>(T), dgi, dgh);
   return check_launch("gru_bwd");
 }

@@ -44,20 +44,19 @@ class _GRULayer(torch.autograd.Function):
         dev = dy.device
         dy = dy.contiguous()
         dgi = torch.empty((B, T, 2, 3 * Hh), dtype=torch.float32, device=dev)
-        dhn = torch.empty((B, T, 2, Hh), dtype=torch.float32, device=dev)
+        dgh = torch.empty((B, T, 2, 3 * Hh), dtype=torch.float32, device=dev)      # (d r_pre, d z_pre, d n_pre * r)
         lib = _lib.load()
         _lib.check(lib.agnn_gru_bwd_f32(dy.data_ptr(), y.data_ptr(), saved.data_ptr(), w_hh.data_ptr(), B, T, Hh,
-                                        dgi.data_ptr(), dhn.data_ptr(), _lib.stream_ptr(dev)), "agnn_gru_bwd_f32")
+                                        dgi.data_ptr(), dgh.data_ptr(), _lib.stream_ptr(dev)), "agnn_gru_bwd_f32")
         dgi2 = dgi.view(B * T, 6 * Hh)
         wf = w_ih.reshape(6 * Hh, I)
         dx = (dgi2 @ wf).view(B, T, I) if ctx.needs_input_grad[0] else None
         # Everything that only feeds the optimizer leaves the recurrence chain (layer l-1's kernel waits for dx alone).
         # Forked AFTER dx is queued: the weight-gradient GEMMs then run beside the next layer's recurrence kernel
         # (64 of 256 CUs) instead of halving the speed of the dx GEMM the chain is waiting for.
-        with wgrad_stream(dev, dgi, dhn, y, x2, active=ctx.wg_async, kind="sequence"):
+        with wgrad_stream(dev, dgi, dgh, y, x2, active=ctx.wg_async, kind="sequence"):
             dw_ih, db_ih = weight_grad(dgi2, x2, True)
             dw_ih, db_ih = dw_ih.view(2, 3 * Hh, I), db_ih.view(2, 3 * Hh)
-            dgh = torch.cat([dgi[..., : 2 * Hh], dhn], dim=-1)                          # [B,T,2,3H]
             hp = torch.zeros((B, T, 2, Hh), dtype=torch.float32, device=dev)             # h_{t-1} per direction
             if T > 1:
                 hp[:, 1:, 0] = y[:, :-1, :Hh]

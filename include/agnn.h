@@ -137,13 +137,14 @@ int agnn_spmm_f32(int n_rel, const agnn_rel_t* rels /* (host) */, int64_t n_rows
  *   w_hh  [2, 3*hidden, hidden], b_hh [2, 3*hidden]
  *   y     [B, T, 2*hidden]      forward | reverse halves, as nn.GRU(batch_first) returns
  *   saved [B, T, 2, 4, hidden]  r, z, n, W_hn h + b_hn  (kept for the backward pass)
- * Backward: given dy emits dgi [B, T, 2, 3*hidden] (gradient w.r.t. gi) and dhn [B, T, 2, hidden]
- * (gradient w.r.t. W_hn h + b_hn); weight/input gradients are GEMMs over those.
+ * Backward: given dy emits dgi [B, T, 2, 3*hidden] (gradient w.r.t. gi) and dgh [B, T, 2, 3*hidden]
+ * (gradient w.r.t. W_hh h + b_hh: the r and z blocks equal dgi's, the n block is d n_pre * r);
+ * weight/input gradients are GEMMs over those.
  * ------------------------------------------------------------------------------------------ */
 int agnn_gru_fwd_f32(const float* gi, const float* w_hh, const float* b_hh, int64_t B, int64_t T,
                      int32_t hidden, float* y, float* saved, agnn_stream_t stream);
 int agnn_gru_bwd_f32(const float* dy, const float* y, const float* saved, const float* w_hh,
-                     int64_t B, int64_t T, int32_t hidden, float* dgi, float* dhn,
+                     int64_t B, int64_t T, int32_t hidden, float* dgi, float* dgh,
                      agnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
