@@ -1,0 +1,63 @@
+"""The captured training step (what bench.py times) computes what the eager step computes: same loss, bit-identical
+gradients, and a replay is reproducible.  C2-shaped model on 8 x 500-note subgraphs, dropout 0 (the dropout masks are
+a function of the device-side step counter, which eager steps and replays advance differently)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_graph_replay_equals_eager_step_and_is_reproducible():
+    from analysisgnn_amd import dp, graph
+    from analysisgnn_amd.heads import multitask_cross_entropy
+    from analysisgnn_amd.models import TorchAnalysisGNN
+    from analysisgnn_amd.synth import make_batch, torch_inputs
+    dev = torch.device("cuda", 0)
+    tasks = {"cadence": 4, "localkey": 50, "romanNumeral": 185, "hrythm": 2, "pcset": 94}
+    g = make_batch(8, 500)
+    I = torch_inputs(g, 25, dev, seed=0)
+    labels = torch.stack([torch.randint(0, c, (I["batch_size"],), generator=torch.Generator().manual_seed(i)).to(dev)
+                          for i, c in enumerate(tasks.values())])
+    torch.manual_seed(0)
+    model = TorchAnalysisGNN(g.metadata(), 25, 256, 128, tasks, 3, dropout=0.0, use_jk=False).to(dev).train()
+    flat = dp.FlatGradBuffer(model.parameters(), views=False)
+    was = graph.index_cache_enabled
+    graph.index_cache_enabled = False
+    dp.enable_wgrad_overlap(True, "sequence")
+    try:
+        def fwd_bwd():
+            flat.zero()
+            x = model.encode(I["pitch_spelling"], I["key_signature"], I["x_dict"], I["edge_index_dict"], I["batch_dict"],
+                             I["batch_size"], None, None)
+            logits, offs, _ = model.forward_clf_fused(x)
+            loss = 0.1 * x.pow(2).mean() + multitask_cross_entropy(logits, offs, labels, 0.1, -1).sum()
+            loss.backward()
+            flat.pack()
+            return loss
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                loss_e = fwd_bwd()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        g_eager, l_eager = flat.flat.clone(), float(loss_e)
+        assert torch.isfinite(g_eager).all() and float(g_eager.abs().max()) > 0
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
+            loss_g = fwd_bwd()
+        flat.flat.zero_()
+        cg.replay()
+        torch.cuda.synchronize()
+        g1, l1 = flat.flat.clone(), float(loss_g)
+        flat.flat.fill_(7.0)                     # a replay must overwrite every gradient slot
+        cg.replay()
+        torch.cuda.synchronize()
+        g2 = flat.flat.clone()
+        assert l1 == l_eager
+        assert torch.equal(g1, g_eager), float((g1 - g_eager).abs().max())
+        assert torch.equal(g1, g2)
+    finally:
+        dp.enable_wgrad_overlap(False)
+        graph.index_cache_enabled = was
