@@ -6,8 +6,9 @@
 // library GEMM against the block-diagonal [sum C, T*64] weight it costs 21x the useful FLOPs (311 + 216 + 243 us
 // for forward / dX / dW per step, profiles/r01_h).  The useful work is tiny (K = 64) and HBM-bound: read a
 // [N, T*64] once, write [N, sum C] once.  Kernels (fp32-input MFMA 32x32x2, one wave = one 32-row x one group item):
-//   k_gproj_fwd  A operand = 32 rows x K/2 contiguous floats per lane (16-byte loads, the two lane halves take the two
-//                halves of the K range), B operand = 32 weight rows likewise; K/2 MFMAs per 32-class tile.
+//   k_gproj_fwd  one workgroup = 128 rows x one group; the `a` tile and each 32-class weight tile go through LDS (coalesced
+//                16-byte loads, weights fetched once per workgroup); A operand = K/2 floats per lane (the two lane halves
+//                take the two halves of the K range), B operand likewise; K/2 MFMAs per 32-class tile.
 //   k_gproj_dx   da[n, g*K + k] = sum_c dout[n, off_g + c] w[off_g + c, k]; the class range is split between the lane halves.
 //   k_gproj_dw   dw[off_g + c, k] = sum_n dout[n, off_g + c] a[n, g*K + k] and db: both operands "n-major", row pairs
 //                per MFMA step, N cut into S slices -> slabs -> agnn::launch_slab_reduce (fixed order, no atomics).
@@ -34,31 +35,56 @@ struct GpArgs {
 
 __device__ __forceinline__ int d_row(int r, int kk) { return (r & 3) + 8 * (r >> 2) + 4 * kk; }   // C/D layout of 32x32 MFMA
 
+// LDS-staged forward: one workgroup = 128 rows x ONE group.  The 128 x K tile of `a` is fetched with coalesced 16-byte
+// loads (16 lanes per 256-byte row piece) and the 32 x K weight tile of each 32-class step once per workgroup (all four
+// waves use it), instead of every lane gathering its own 128-byte row piece from global memory (profiles/r01_gproj_pmc.md:
+// 40 % of the wave cycles waited on those gathers).  Row stride K + 4 floats keeps the 16-byte LDS reads at 2-way conflicts.
 template <int K>
 __global__ __launch_bounds__(256) void k_gproj_fwd(GpArgs p) {
-  constexpr int KH = K / 2;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t item = static_cast<int64_t>(blockIdx.x) * 4 + wave;
-  const int rt = static_cast<int>(item / p.G), g = static_cast<int>(item - static_cast<int64_t>(rt) * p.G);
-  if (rt >= p.n_row_tiles) return;
+  constexpr int KH = K / 2, LDA = K + 4;
+  __shared__ __attribute__((aligned(16))) float sA[128 * LDA];
+  __shared__ __attribute__((aligned(16))) float sW[2][32 * LDA];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rb = blockIdx.x / p.G, g = blockIdx.x - rb * p.G;
   const int j = lane & 31, kk = lane >> 5;
   const int off = p.seg_off[g], C = p.seg_off[g + 1] - off;
   if (C <= 0) return;
-  int64_t row = static_cast<int64_t>(rt) * 32 + j;
-  if (row > p.n_rows - 1) row = p.n_rows - 1;
-  float av[KH];
-  const float4* ap = reinterpret_cast<const float4*>(p.a + row * p.ld_a + g * K + kk * KH);
+  constexpr int F4 = K / 4;                           // float4 per row
+  constexpr int RPP = 256 / F4;                       // rows per pass of the whole workgroup
+  const int lr = tid / F4, lc = tid - lr * F4;
 #pragma unroll
-  for (int q = 0; q < KH / 4; ++q) {
-    const float4 v = ap[q];
-    av[4 * q] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
+  for (int r0 = 0; r0 < 128; r0 += RPP) {
+    int64_t row = static_cast<int64_t>(rb) * 128 + r0 + lr;
+    if (row > p.n_rows - 1) row = p.n_rows - 1;
+    const float4 v = *reinterpret_cast<const float4*>(p.a + row * p.ld_a + g * K + 4 * lc);
+    *reinterpret_cast<float4*>(&sA[(r0 + lr) * LDA + 4 * lc]) = v;
   }
-  for (int ct = 0; ct * 32 < C; ++ct) {
-    const int col = ct * 32 + j;
-    const int c = col < C ? col : C - 1;
-    const float4* wp = reinterpret_cast<const float4*>(p.w + static_cast<int64_t>(off + c) * K + kk * KH);
+  auto load_w = [&](int ct, int buf) {
+#pragma unroll
+    for (int r0 = 0; r0 < 32; r0 += RPP) {
+      const int c = ct * 32 + r0 + lr;
+      const int cc = c < C ? c : C - 1;
+      const float4 v = *reinterpret_cast<const float4*>(p.w + static_cast<int64_t>(off + cc) * K + 4 * lc);
+      *reinterpret_cast<float4*>(&sW[buf][(r0 + lr) * LDA + 4 * lc]) = v;
+    }
+  };
+  const int n_ct = (C + 31) >> 5;
+  load_w(0, 0);
+  __syncthreads();
+  float av[KH];
+  {
+    const float4* ap = reinterpret_cast<const float4*>(&sA[(wave * 32 + j) * LDA + kk * KH]);
+#pragma unroll
+    for (int q = 0; q < KH / 4; ++q) {
+      const float4 v = ap[q];
+      av[4 * q] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
+    }
+  }
+  for (int ct = 0; ct < n_ct; ++ct) {
+    const int buf = ct & 1;
+    if (ct + 1 < n_ct) load_w(ct + 1, buf ^ 1);       // next weight tile into the other buffer while this one is used
     float bv[KH];
+    const float4* wp = reinterpret_cast<const float4*>(&sW[buf][j * LDA + kk * KH]);
 #pragma unroll
     for (int q = 0; q < KH / 4; ++q) {
       const float4 v = wp[q];
@@ -67,14 +93,16 @@ __global__ __launch_bounds__(256) void k_gproj_fwd(GpArgs p) {
     f32x16 acc = {0};
 #pragma unroll
     for (int s = 0; s < KH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+    const int col = ct * 32 + j;
     if (col < C) {
       const float bias = p.b != nullptr ? p.b[off + col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t ro = static_cast<int64_t>(rt) * 32 + d_row(r, kk);
+        const int64_t ro = static_cast<int64_t>(rb) * 128 + wave * 32 + d_row(r, kk);
         if (ro < p.n_rows) p.out[ro * p.ld_out + off + col] = acc[r] + bias;
       }
     }
+    __syncthreads();                                   // buffer `buf` free for tile ct + 2, tile ct + 1 visible
   }
 }
 
@@ -235,9 +263,9 @@ extern "C" int agnn_gproj_fwd_f32(const float* a, int64_t ld_a, const float* w, 
   p.a = a; p.w = w; p.b = b; p.seg_off = seg_off; p.out = out;
   p.ld_a = ld_a; p.ld_out = ld_out; p.n_rows = n_rows; p.G = n_groups;
   p.n_row_tiles = static_cast<int32_t>((n_rows + 31) / 32);
-  const int64_t items = static_cast<int64_t>(p.n_row_tiles) * n_groups;
-  const dim3 grid(static_cast<unsigned>((items + 3) / 4));
   hipStream_t s = static_cast<hipStream_t>(stream_);
+  const int64_t row_blocks = (n_rows + 127) / 128;
+  const dim3 grid(static_cast<unsigned>(row_blocks * n_groups));
   if (K == 32) hipLaunchKernelGGL(k_gproj_fwd<32>, grid, dim3(256), 0, s, p);
   else if (K == 64) hipLaunchKernelGGL(k_gproj_fwd<64>, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(k_gproj_fwd<128>, grid, dim3(256), 0, s, p);
