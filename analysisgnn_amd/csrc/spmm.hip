@@ -312,10 +312,285 @@ __global__ __launch_bounds__(256) void k_spmm_fast(RelTable t, SpmmArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Fast path, straight-line index phase.  PMC on k_spmm_fast (profiles/r01_spmm_kernel_study.md, second part): at
+// full occupancy (8 waves / SIMD) a wave lives ~6 us, 55 % of it in s_waitcnt, and the launch takes two such
+// rounds — the kernel is bound by the LENGTH OF THE DEPENDENT-LOAD CHAIN of one row, not by bytes.  The chain in
+// k_spmm_fast: per relation {pointer from the kernel-argument table -> rowptr[row] -> rowptr[row+1]} one after the
+// other, then the column ids, then per relation {gather -> store}, with every later gather also waiting for the
+// previous relation's store (vmcnt counts loads and stores in issue order).  Here:
+//   * the table is a structure of arrays, so the four rowptr / col / src pointers come with one scalar load each,
+//     and entries beyond n_rel repeat the last relation: no branch anywhere in the index phase;
+//   * all four rowptr pairs are one batch of scalar loads, all four column-id vectors one batch of vector loads,
+//     the first two neighbour rows of all four relations (8 loads; rows have ~1.6 neighbours per relation) one
+//     batch, and the 1/deg column scales of the backward pass travel with that batch;
+//   * nothing is stored before every gather of the row has been issued.
+// A row therefore costs rowptr -> col -> gather.  Loads are unconditional: lanes beyond the neighbour count repeat
+// the last neighbour (an L1 hit) or, for an empty segment, row 0, and what they fetch is dropped by a per-lane
+// select (not a multiply by zero: a non-finite value must not leak).  Neighbours beyond the second (rare) take the
+// two-at-a-time loop of k_spmm_fast.
+// ------------------------------------------------------------------------------------------
+struct FastTable {
+  const int32_t* rowptr[AGNN_MAX_SEG + 3];
+  const int32_t* col[AGNN_MAX_SEG + 3];
+  const float* src[AGNN_MAX_SEG + 3];
+  const float* colscale[AGNN_MAX_SEG + 3];
+  uint32_t ldb[AGNN_MAX_SEG + 4];     // row stride in bytes (< 4 GiB, host-checked)
+  int n_rel;
+};
+
+__device__ __forceinline__ int to_vgpr(int s) {
+  int v;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+  return v;
+}
+__device__ __forceinline__ float4 f4_keep(bool keep, const float4& v) {
+  return make_float4(keep ? v.x : 0.f, keep ? v.y : 0.f, keep ? v.z : 0.f, keep ? v.w : 0.f);
+}
+
+typedef const __attribute__((address_space(4))) float* k_f32p;
+
+template <int CH, int RPW, bool HAS_CS, bool SHARED, bool SELF>
+__global__ __launch_bounds__(256) void k_spmm_fast6(FastTable t, SpmmArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int vb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-contiguous row slabs
+  const int row0 = (vb * 4 + wave) * RPW;          // RPW consecutive rows per wave share the index phase
+  if (row0 >= a.n_rows) return;
+  const bool mean = (a.flags & AGNN_SPMM_MEAN) != 0;
+  const uint32_t loff = static_cast<uint32_t>(lane) * 16u;
+  int rowj[RPW];                                   // rows past the end repeat the last row for loads; never stored
+#pragma unroll
+  for (int j = 0; j < RPW; ++j) rowj[j] = row0 + j < a.n_rows ? row0 + j : a.n_rows - 1;
+
+  float4 selfv[SELF ? RPW : 1][SELF ? CH : 1];
+  if (SELF) {
+#pragma unroll
+    for (int j = 0; j < (SELF ? RPW : 1); ++j) {
+      const char* sp = reinterpret_cast<const char*>(a.self + static_cast<int64_t>(rowj[j]) * a.ld_self);
+#pragma unroll
+      for (int c = 0; c < (SELF ? CH : 1); ++c) selfv[j][c] = *reinterpret_cast<const float4*>(sp + (loff + c * 1024u));
+    }
+  }
+  float4 tot[SHARED ? RPW : 1][SHARED ? CH : 1];
+#pragma unroll
+  for (int j = 0; j < (SHARED ? RPW : 1); ++j)
+#pragma unroll
+    for (int c = 0; c < (SHARED ? CH : 1); ++c) tot[j][c] = f4_zero();
+
+  for (int r0 = 0; r0 < t.n_rel; r0 += 4) {
+    // ---- index phase: no control flow; the empty asm statements pin "all pointers, then all rowptr entries, then
+    //      all column ids" (left alone, the compiler sinks each scalar load to its first use: one trip per relation)
+    k_i32p rpp[4];
+    const int32_t* cpp[4];
+    const char* srcp[4];
+    const float* csp[4];
+    uint32_t ldbv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      rpp[u] = (k_i32p)t.rowptr[r0 + u];
+      cpp[u] = t.col[r0 + u];
+      srcp[u] = reinterpret_cast<const char*>(t.src[r0 + u]);
+      csp[u] = HAS_CS ? t.colscale[r0 + u] : nullptr;
+      ldbv[u] = t.ldb[r0 + u];
+    }
+    asm volatile("" ::"s"(rpp[0]), "s"(rpp[1]), "s"(rpp[2]), "s"(rpp[3]), "s"(cpp[0]), "s"(cpp[1]), "s"(cpp[2]), "s"(cpp[3]));
+    asm volatile("" ::"s"(srcp[0]), "s"(srcp[1]), "s"(srcp[2]), "s"(srcp[3]), "s"(ldbv[0]), "s"(ldbv[1]), "s"(ldbv[2]), "s"(ldbv[3]));
+    if (HAS_CS) asm volatile("" ::"s"(csp[0]), "s"(csp[1]), "s"(csp[2]), "s"(csp[3]));
+    int ext[4][RPW + 1];                           // rowptr[row0 .. row0 + RPW], clamped to n_rows: rows past the end are empty
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j <= RPW; ++j) ext[u][j] = rpp[u][row0 + j < a.n_rows ? row0 + j : a.n_rows];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int j = 0; j <= RPW; ++j) asm volatile("" ::"s"(ext[u][j]));
+    }
+    int n[RPW][4], off[RPW][4], span[4];
+    int colv[4];
+    float wv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int live = r0 + u < t.n_rel ? -1 : 0;   // mask, not a branch: the tail entries of the table are valid duplicates
+#pragma unroll
+      for (int j = 0; j < RPW; ++j) {
+        n[j][u] = (ext[u][j + 1] - ext[u][j]) & live;
+        off[j][u] = ext[u][j] - ext[u][0];
+      }
+      span[u] = (ext[u][RPW] - ext[u][0]) & live;
+      colv[u] = 0;
+      if (lane < span[u]) colv[u] = cpp[u][ext[u][0] + lane];
+    }
+#define AGNN_OVF(j, u) (off[j][u] + n[j][u] > 64)  /* segment not (entirely) among the 64 ids held in registers */
+    // ---- row after row on the same registers: the index phase above is paid once per wave, a further row costs one
+    //      gather round trip
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+      if (row0 + j >= a.n_rows) break;
+      // the first two neighbour rows of every relation
+      float4 v0[4][CH], v1[4][CH];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint64_t ldb = ldbv[u];
+        const int p0 = off[j][u] < 63 ? off[j][u] : 63;
+        int step;                                  // 1 when the segment has >= 2 neighbours, else the second load repeats the first
+        asm("s_sub_i32 %0, 1, %1\n\ts_lshr_b32 %0, %0, 31" : "=s"(step) : "s"(n[j][u]) : "scc");
+        const int p1 = RPW == 1 ? step : (p0 + step < 63 ? p0 + step : 63);
+        const uint32_t c0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(colv[u], p0));
+        const uint32_t c1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(colv[u], p1));
+        const char* b0 = srcp[u] + c0 * ldb;       // column ids are non-negative: one s_mul + one s_mul_hi
+        const char* b1 = srcp[u] + c1 * ldb;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) v0[u][c] = *reinterpret_cast<const float4*>(b0 + (loff + c * 1024u));
+#pragma unroll
+        for (int c = 0; c < CH; ++c) v1[u][c] = *reinterpret_cast<const float4*>(b1 + (loff + c * 1024u));
+        if (HAS_CS && j == 0) {                    // the 1/deg scales travel with the first row's gathers
+          wv[u] = 0.f;
+          if (lane < span[u]) wv[u] = csp[u][colv[u]];
+        }
+        __builtin_amdgcn_sched_barrier(0);         // every gather is issued before the first one is waited for, and
+      }                                            // address registers are recycled from pair to pair
+      // reduce (in place: v0 becomes the accumulator)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int nv = to_vgpr(AGNN_OVF(j, u) ? 0 : n[j][u]);
+        float w0 = 1.f, w1 = 1.f;
+        if (HAS_CS) {
+          const int p0 = off[j][u] < 63 ? off[j][u] : 63;
+          w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv[u]), p0));
+          w1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv[u]), p0 < 63 ? p0 + 1 : 63));
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const float4 k0 = f4_keep(nv > 0, v0[u][c]), k1 = f4_keep(nv > 1, v1[u][c]);
+          if (HAS_CS) {
+            v0[u][c] = make_float4(w0 * k0.x, w0 * k0.y, w0 * k0.z, w0 * k0.w);
+            f4_fma(v0[u][c], w1, k1);
+          } else {
+            v0[u][c] = make_float4(k0.x + k1.x, k0.y + k1.y, k0.z + k1.z, k0.w + k1.w);
+          }
+        }
+      }
+      // third and later neighbours (and segments whose ids are not in registers), two at a time
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int nn = n[j][u];
+        if (nn > 2 || AGNN_OVF(j, u)) {
+          const uint64_t ldb = ldbv[u];
+          const bool in_regs = !AGNN_OVF(j, u);
+          const k_i32p colg = (k_i32p)cpp[u] + ext[u][j];
+          for (int k = in_regs ? 2 : 0; k < nn; k += 2) {
+            const bool two = k + 1 < nn;
+            const int ka = k, kb = two ? k + 1 : k;
+            uint32_t c0, c1;
+            float x0 = 1.f, x1 = 1.f;
+            if (in_regs) {
+              c0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(colv[u], off[j][u] + ka));
+              c1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(colv[u], off[j][u] + kb));
+              if (HAS_CS) {
+                x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv[u]), off[j][u] + ka));
+                x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv[u]), off[j][u] + kb));
+              }
+            } else {                               // > 64 neighbours in the wave's rows of this relation: scalar loads
+              c0 = static_cast<uint32_t>(colg[ka]);
+              c1 = static_cast<uint32_t>(colg[kb]);
+              if (HAS_CS) {
+                x0 = ((k_f32p)csp[u])[c0];
+                x1 = ((k_f32p)csp[u])[c1];
+              }
+            }
+            const char* b0 = srcp[u] + c0 * ldb;
+            const char* b1 = srcp[u] + c1 * ldb;
+            float4 q0[CH], q1[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) q0[c] = *reinterpret_cast<const float4*>(b0 + (loff + c * 1024u));
+#pragma unroll
+            for (int c = 0; c < CH; ++c) q1[c] = *reinterpret_cast<const float4*>(b1 + (loff + c * 1024u));
+            const int twov = to_vgpr(two ? 1 : 0);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+              f4_fma(v0[u][c], x0, q0[c]);
+              f4_fma(v0[u][c], x1, f4_keep(twov != 0, q1[c]));
+            }
+          }
+        }
+      }
+      // scale and store.  1 / max(count, 1) of the four relations is computed once, in lanes 0..3 (v_rcp_f32, <= 1 ulp),
+      // stored by those lanes with one instruction and broadcast back as scalars.
+      int nvec = 1;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int cnt = n[j][u] > 1 ? n[j][u] : 1;
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(nvec) : "s"(cnt), "n"(u));
+      }
+      const float invv = __builtin_amdgcn_rcpf(static_cast<float>(nvec));
+      if (a.inv_cnt != nullptr && lane < 4 && r0 + lane < t.n_rel)
+        a.inv_cnt[static_cast<int64_t>(r0 + lane) * a.n_rows + (row0 + j)] = invv;
+      const float scalev = mean ? invv : 1.f;      // sums: x * 1.f is exact
+      char* op = reinterpret_cast<char*>(a.out + static_cast<int64_t>(row0 + j) * a.ld_out + static_cast<int64_t>(r0) * a.rel_stride) + loff;
+      const int64_t op_step = a.rel_stride * 4;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (r0 + u >= t.n_rel) break;
+        const float inv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(scalev), u));
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          float4& o = v0[u][c];
+          if (SELF) f4_add(o, selfv[SELF ? j : 0][SELF ? c : 0]);
+          o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
+        }
+        if (SHARED) {
+#pragma unroll
+          for (int c = 0; c < CH; ++c) f4_add(tot[SHARED ? j : 0][SHARED ? c : 0], v0[u][c]);
+        } else {
+#pragma unroll
+          for (int c = 0; c < CH; ++c) *reinterpret_cast<float4*>(op + c * 1024) = v0[u][c];
+          op += op_step;
+        }
+      }
+    }
+#undef AGNN_OVF
+  }
+  if (SHARED) {
+#pragma unroll
+    for (int j = 0; j < (SHARED ? RPW : 1); ++j) {
+      if (row0 + j >= a.n_rows) break;
+      char* op = reinterpret_cast<char*>(a.out + static_cast<int64_t>(row0 + j) * a.ld_out);
+#pragma unroll
+      for (int c = 0; c < CH; ++c) *reinterpret_cast<float4*>(op + (loff + c * 1024u)) = tot[j][SHARED ? c : 0];
+    }
+  }
+}
+
 template <int CH>
-void launch_fast(dim3 grid, hipStream_t stream, const RelTable& t, const SpmmArgs& a, bool has_cs) {
+void launch_fast(hipStream_t stream, const RelTable& t, const SpmmArgs& a, bool has_cs) {
   const bool shared = a.rel_stride == 0, self = a.self != nullptr;
-#define AGNN_FAST(CS, SH, SE) hipLaunchKernelGGL((k_spmm_fast<CH, CS, SH, SE>), grid, dim3(256), 0, stream, t, a)
+  const bool v4 = (a.flags & AGNN_SPMM_FAST_V4) != 0 || (a.flags & AGNN_SPMM_ACCUM) != 0;
+  // Rows per wave.  More than one (consecutive rows sharing one index phase) measured SLOWER at the C2 shape, both with
+  // the rows' gathers in flight together (95 VGPRs -> 5 waves / SIMD: forward 17.1 us vs 15.5 us) and one row after
+  // the other on the same registers (16.5 us; backward 18.1 vs 15.5 us): vmcnt counts in issue order, so the second
+  // row's gathers cannot be consumed before the first row's stores are acknowledged, whereas a wave that ends after
+  // its stores hands its slot to a new wave at once.  The kernel keeps the RPW parameter; only 1 is instantiated.
+  constexpr int rpw = 1;
+  const int rows_per_block = 4 * rpw;
+  const dim3 grid(static_cast<unsigned>(((a.n_rows + rows_per_block - 1) / rows_per_block + 7) & ~7));   // multiple of 8: the XCD remap is a bijection
+  FastTable f{};
+  f.n_rel = t.n_rel;
+  for (int r = 0; r < AGNN_MAX_SEG + 3; ++r) {
+    const agnn_rel_t& R = t.r[r < t.n_rel ? r : t.n_rel - 1];     // the tail repeats the last relation: loads stay valid
+    f.rowptr[r] = R.rowptr;
+    f.col[r] = R.col;
+    f.src[r] = R.src;
+    f.colscale[r] = R.colscale;
+    f.ldb[r] = static_cast<uint32_t>(R.ld_src * 4);
+  }
+#define AGNN_FAST(CS, SH, SE)                                                                                     \
+  do {                                                                                                            \
+    if (v4) hipLaunchKernelGGL((k_spmm_fast<CH, CS, SH, SE>), grid, dim3(256), 0, stream, t, a);                  \
+    else hipLaunchKernelGGL((k_spmm_fast6<CH, rpw, CS, SH, SE>), grid, dim3(256), 0, stream, f, a);               \
+  } while (0)
   if (has_cs) {
     if (shared && self) AGNN_FAST(true, true, true); else if (shared) AGNN_FAST(true, true, false);
     else if (self) AGNN_FAST(true, false, true); else AGNN_FAST(true, false, false);
@@ -363,13 +638,14 @@ extern "C" int agnn_spmm_f32(int n_rel, const agnn_rel_t* rels, int64_t n_rows, 
       col_limit == INT32_MAX) {
     bool plain = true, any_cs = false, all_cs = true;
     for (int r = 0; r < n_rel; ++r) {
-      plain = plain && rels[r].rowend == nullptr && rels[r].ew == nullptr && rels[r].src != nullptr && rels[r].col != nullptr;
+      plain = plain && rels[r].rowend == nullptr && rels[r].ew == nullptr && rels[r].src != nullptr && rels[r].col != nullptr &&
+              rels[r].ld_src < (int64_t{1} << 30);
       any_cs = any_cs || rels[r].colscale != nullptr;
       all_cs = all_cs && rels[r].colscale != nullptr;
     }
     if (plain && any_cs == all_cs) {
-      if (H == 256) launch_fast<1>(dim3(blocks), stream, t, a, all_cs);
-      else launch_fast<2>(dim3(blocks), stream, t, a, all_cs);
+      if (H == 256) launch_fast<1>(stream, t, a, all_cs);
+      else launch_fast<2>(stream, t, a, all_cs);
       return check_launch("spmm(fast)");
     }
   }

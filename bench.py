@@ -266,7 +266,7 @@ def main():
                                    "(4 note-note relations, %d edges), train step fwd+loss+bwd+allreduce+clip+AdamW, "
                                    "CSR rebuilt every step; " % e_tot + ("hipGraph replay" if graphs is not None else "eager launches"), "per_gpu_subgraphs": N_SUB, "notes_per_subgraph": N_NOTES,
                        "parallelism": f"dp{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k_spmm_fast<1,false,false,false> forward hetero-SpMM (R=4, N=16000, H=256 -> [N,4H])",
+            "roofline": {"bound": "hbm", "kernel": "k_spmm_fast6<1,1,false,false,false> forward hetero-SpMM (R=4, N=16000, H=256 -> [N,4H])",
                          "achieved": b_alg / t_fwd / 1e9 if t_fwd > 0 else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": (b_alg / t_fwd) / HBM_PEAK if t_fwd > 0 else None,
                          # HBM bytes per launch from rocprofv3 PMC passes of this kernel at this shape (FETCH_SIZE x2 gfx950

@@ -122,6 +122,7 @@ typedef struct {
 #define AGNN_SPMM_SKIP_SELF 2u
 #define AGNN_SPMM_ACCUM     4u
 #define AGNN_SPMM_GENERIC 1024u /* never take the specialised fast path (tests / A/B timing) */
+#define AGNN_SPMM_FAST_V4 2048u /* fast path: the older one-relation-at-a-time kernel (A/B timing) */
 
 int agnn_spmm_f32(int n_rel, const agnn_rel_t* rels /* (host) */, int64_t n_rows, int32_t H,
                   float* out, int64_t ld_out, int64_t rel_stride,

@@ -34,8 +34,8 @@ def main():
     b_bwd = sum(4 * (N + 1) + 4 * b.edge_index[e].shape[1] + 4 * N for e in ets) + 4 * H * (R * N + N)
     res = {}
     for rnd in range(12):
-        for legacy in ("generic", "fast"):
-            ops.SPMM_VARIANT = {"generic": 1024, "fast": 0}[legacy]
+        for legacy in ("generic", "fast_v4", "fast"):
+            ops.SPMM_VARIANT = {"generic": 1024, "fast_v4": 2048, "fast": 0}[legacy]
             ops.SPMM_TRACE = []
             for _ in range(10):
                 x.grad = None

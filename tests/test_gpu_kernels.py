@@ -140,6 +140,9 @@ def test_spmm_heavy_row_and_empty_rows():
     # one destination with > 64 neighbours (several col batches), many rows without any edge
     from analysisgnn_amd import _lib
     _spmm_case(40, 500, [3000], 256, mean=True, shared=False, with_self=False, seed=3)
+    # the same through the backward configuration of the fast path (column scales, relations summed into one slot)
+    _spmm_case(40, 500, [3000, 70], 256, mean=False, shared=True, with_self=False, seed=4, colscale=True)
+    _spmm_case(33, 500, [2500, 0, 9], 512, mean=True, shared=False, with_self=True, seed=5)
 
 
 def test_spmm_filters_and_trim():
