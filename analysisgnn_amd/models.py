@@ -13,7 +13,7 @@ import torch.nn as nn
 from . import _lib, ops
 from .encoders import HybridGNN, MetricalGNN
 from .fused import FusedSequential, advance_rng
-from .embedding import embedding
+from .embedding import embed_cat
 from .heads import fused_head_logits
 from .linear import Linear
 from .graph import SegSpec, build_csr
@@ -84,13 +84,9 @@ class TorchAnalysisGNN(nn.Module):
         if self.training:
             advance_rng(x_dict["note"].device)          # fresh dropout masks for this step (device-side counter)
         z_dict = dict(x_dict)
-        xn = z_dict["note"]
-        parts = [xn, embedding(pitch_spelling, self.pitch_embedding.weight), embedding(key_signature, self.key_embedding.weight)]
-        width = sum(int(t.shape[1]) for t in parts)
-        pad = (-width) % 4                               # rows padded to 16 bytes; the spare columns are zero and stay out of the view
-        if pad:
-            parts.append(xn.new_zeros((xn.shape[0], pad)))
-        z_dict["note"] = torch.cat(parts, dim=-1)[:, :width]
+        # analysis.py:574 — one launch; rows padded to 16 bytes (the spare columns are zero and stay out of the view)
+        z_dict["note"] = embed_cat(z_dict["note"], [pitch_spelling, key_signature],
+                                   [self.pitch_embedding.weight, self.key_embedding.weight])
         h_dict = {k: self.project_dict[k](z_dict[k]) for k in self.project_dict.keys()}
         x = self.encoder(x_dict=h_dict, edge_index_dict=edge_index_dict, batch_dict=batch_dict,
                          batch_size=batch_size, neighbor_mask_node=neighbor_mask_node,

@@ -19,6 +19,8 @@
  *   agnn_norm_act_*       LayerNorm / ReLU / Dropout chains between the projections (ref: models/analysis.py:429-443)
  *   agnn_wgrad_f32        weight/bias gradients of the dense projections (fp32 MFMA, split over N)
  *   agnn_pack_f32         per-relation parameter cat / sum / gradient fan-out of the fused HeteroConv (ref: models/cadence.py:147-159)
+ *   agnn_embed_cat_*      note-input assembly `cat([x, pitch_embedding(ps), key_embedding(ks)])` and the tables' gradient
+ *                         (ref: models/analysis.py:399-400, :574)
  *   agnn_gproj_*          the task heads' last Linear layers as one grouped projection (ref: models/analysis.py:486-496)
  *   agnn_adamw_f32        gradient clipping + `torch.optim.AdamW` step on the flat buffers (ref: models/analysis.py:1380-1381)
  *   agnn_multitask_ce_f32 the 21 per-task CrossEntropyLoss terms (ref: models/analysis.py:881-888)
@@ -269,6 +271,27 @@ typedef struct {
   int32_t rows, cols, n_src, vec_ok;
 } agnn_pack_item_t;
 int agnn_pack_f32(int32_t n_items, const agnn_pack_item_t* items /* (host) */, agnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Note-input assembly (ref: models/analysis.py:574 `torch.cat([x_dict["note"], self.pitch_embedding(pitch_spelling),
+ * self.key_embedding(key_signature)], dim=-1)`; tables models/analysis.py:399-400) and the gradient of the tables.
+ *   forward   out[n, :] = [ x[n, 0:in_x] | tables[0][idx[0][n], :] | ... | tables[n_tab-1][idx[n_tab-1][n], :] | 0 ... ]
+ *             x [n_rows, in_x] (ld_x), idx[t] DEVICE int64 [n_rows] (ids outside [0, vocab[t]) are clamped — torch raises
+ *             a device assert there), tables[t] DEVICE [vocab[t], dim] contiguous, out [n_rows, ld_out] with
+ *             ld_out >= in_x + n_tab*dim; the columns behind the last table are zero-filled.
+ *   backward  dtables[vbase_t + v, :] = sum_{n: idx[t][n] == v} dout[n, col0 + t*dim : col0 + (t+1)*dim]  with
+ *             vbase_t = vocab[0] + ... + vocab[t-1]; dtables DEVICE [sum vocab, dim] contiguous; dim even.  Rows are
+ *             added in row order inside 32 row slices that are summed in a fixed order (no atomics, reproducible).
+ * `idx`, `tables`, `vocab` are HOST arrays (of device pointers / sizes) read during the call.
+ * ------------------------------------------------------------------------------------------ */
+#define AGNN_EMBED_MAX_TABLES 4
+int agnn_embed_cat_fwd_f32(const float* x, int64_t ld_x, int32_t in_x, int64_t n_rows, int32_t n_tab,
+                           const int64_t* const* idx, const float* const* tables, const int32_t* vocab, int32_t dim,
+                           float* out, int64_t ld_out, agnn_stream_t stream);
+size_t agnn_embed_workspace_bytes(int32_t n_tab, const int32_t* vocab, int32_t dim);
+int agnn_embed_cat_bwd_f32(const float* dout, int64_t ld_dout, int32_t col0, int64_t n_rows, int32_t n_tab,
+                           const int64_t* const* idx, const int32_t* vocab, int32_t dim, float* dtables,
+                           void* workspace, size_t workspace_bytes, agnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Grouped projection: the last Linear(h2 -> C_t) of all task heads in one launch per direction

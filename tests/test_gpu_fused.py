@@ -120,6 +120,40 @@ def test_small_embedding_backward_matches_library():
         assert_close(w.grad, w2.grad, 1e-5, f"dW V={V} N={N}")
 
 
+@pytest.mark.parametrize("n,in_x,vocabs,dim", [(16000, 25, (35, 15), 64), (4097, 25, (35, 15), 64), (5, 3, (7,), 8),
+                                                 (333, 0, (4, 9, 2), 6), (64, 56, (35, 15), 64)])
+def test_embed_cat_matches_torch(n, in_x, vocabs, dim):
+    """analysisgnn_amd.embedding.embed_cat (agnn_embed_cat_fwd/bwd_f32) against cat([x, F.embedding(...), ...]) and torch's
+    embedding backward (analysis.py:574): forward bit-identical, table gradients to 1e-5 (different summation order)."""
+    from analysisgnn_amd.embedding import embed_cat
+    torch.manual_seed(n + dim)
+    x = torch.randn(n, in_x, device=DEV)
+    tabs = [torch.randn(v, dim, device=DEV, requires_grad=True) for v in vocabs]
+    tabs2 = [t.detach().clone().requires_grad_(True) for t in tabs]
+    idxs = [torch.randint(0, v, (n,), device=DEV) for v in vocabs]
+    if vocabs[0] > 3:
+        idxs[0][idxs[0] == 2] = 1                           # a table row nobody uses: its gradient must be exactly zero
+    out = embed_cat(x, idxs, tabs)
+    ref = torch.cat([x] + [F.embedding(i, t) for i, t in zip(idxs, tabs2)], dim=-1)
+    assert out.shape == ref.shape and torch.equal(out, ref)
+    assert out.stride(0) % 4 == 0                           # rows padded to 16 bytes ...
+    if out.stride(0) > out.shape[1]:                        # ... with zeros behind the view
+        full = out.as_strided((n, out.stride(0)), (out.stride(0), 1))
+        assert torch.count_nonzero(full[:, out.shape[1]:]) == 0
+    g = torch.randn(n, ref.shape[1], device=DEV)
+    out.backward(g)
+    ref.backward(g)
+    for k, (a, b) in enumerate(zip(tabs, tabs2)):
+        assert_close(a.grad, b.grad, 1e-5, f"dTable{k}")
+    if vocabs[0] > 3:
+        assert torch.count_nonzero(tabs[0].grad[2]) == 0
+    # same launch twice: bitwise reproducible (no atomics)
+    g1 = tabs[0].grad.clone()
+    tabs[0].grad = None
+    embed_cat(x, idxs, tabs).backward(g)
+    assert torch.equal(tabs[0].grad, g1)
+
+
 def test_fused_clip_adamw_matches_torch():
     """agnn_adamw_f32 (dp.FlatAdamW.step on a GPU) against clip_grad_norm_ + torch.optim.AdamW over several steps."""
     from analysisgnn_amd import dp
