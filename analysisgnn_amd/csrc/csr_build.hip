@@ -1,8 +1,21 @@
 // COO (int64, unsorted) -> CSR (int32, stable) for up to AGNN_MAX_SEG relation-directions in
-// ONE pass: a single key space (segment row base + row), one stable radix sort, one boundary
-// scan.  Replaces the reference's per-relation boolean-mask compaction
-// (analysisgnn/models/core/hgnn.py:137-139, :481-483) and the unsorted-index scatter inside
+// ONE pass over a single key space (segment row base + row).  Replaces the reference's per-relation boolean-mask
+// compaction (analysisgnn/models/core/hgnn.py:137-139, :481-483) and the unsorted-index scatter inside
 // torch_scatter.  Pure integer work, HBM/L2-bound; no float math here.
+//
+// A counting sort with a per-row fix-up instead of a library sort: for ~2 x 10^5 edges the library's stable sort is
+// a chain of ~20 tiny merge kernels (~0.2 ms on the critical path of every step, profiles/r01_q); rows of a score
+// graph hold a handful of edges, so
+//   k_count    key per edge, integer atomicAdd into the per-row counters
+//   scan       exclusive sum of the counters = rowstart (library scan)
+//   k_scatter  edge id -> rowstart[key] + slot, slot handed out by atomicSub on the same counters (which are zero
+//              again afterwards); the order INSIDE a row is whatever the atomics gave ...
+//   k_rows     ... and is made the stable one here: one thread per row sorts its <= 32 edge ids in place and emits
+//              col / perm; longer rows go to a list
+//   k_heavy    one wavefront per listed row: rank of every id among the row's ids (O(d^2 / 64)), col / perm written at
+//              the rank; also zero-fills the slots behind the kept edges
+// Integer atomics only decide intermediate positions; the result is the unique stable order (bit-identical to the
+// oracle's), whatever the interleaving.
 #include <hipcub/hipcub.hpp>
 
 #include "agnn_common.h"
@@ -26,8 +39,8 @@ __device__ __forceinline__ int find_seg(const SegTable& t, int32_t e) {
   return s;
 }
 
-// key = global row id (sentinel total_rows for masked-out / out-of-range edges), val = global edge slot
-__global__ void k_make_keys(SegTable t, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+// key = global row id (sentinel total_rows for masked-out / out-of-range edges); counts the kept edges of every row
+__global__ void k_count(SegTable t, uint32_t* __restrict__ keys, uint32_t* __restrict__ cnt) {
   const int32_t e_total = t.ebase[t.n_seg];
   const uint32_t sentinel = static_cast<uint32_t>(t.rbase[t.n_seg]);
   for (int32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < e_total; e += gridDim.x * blockDim.x) {
@@ -37,39 +50,100 @@ __global__ void k_make_keys(SegTable t, uint32_t* __restrict__ keys, uint32_t* _
     const int32_t nrows = t.rbase[s + 1] - t.rbase[s];
     bool keep = r >= 0 && r < nrows;
     if (t.etype[s] != nullptr) keep = keep && (t.etype[s][le] == t.code[s]);
-    keys[e] = keep ? static_cast<uint32_t>(t.rbase[s] + static_cast<int32_t>(r)) : sentinel;
-    vals[e] = static_cast<uint32_t>(e);
+    const uint32_t key = keep ? static_cast<uint32_t>(t.rbase[s] + static_cast<int32_t>(r)) : sentinel;
+    keys[e] = key;
+    if (keep) atomicAdd(cnt + key, 1u);
   }
 }
 
-// rowstart[q] = first sorted position whose key >= q, for q in [0, total_rows]
-__global__ void k_rowstart(const uint32_t* __restrict__ keys, int32_t e_total, int32_t total_rows,
-                           int32_t* __restrict__ rowstart) {
-  for (int32_t p = blockIdx.x * blockDim.x + threadIdx.x; p <= e_total; p += gridDim.x * blockDim.x) {
-    const int64_t k_prev = (p == 0) ? -1 : static_cast<int64_t>(keys[p - 1]);
-    const int64_t k_here = (p == e_total) ? static_cast<int64_t>(total_rows)
-                                          : static_cast<int64_t>(keys[p]);
-    int64_t hi = k_here < total_rows ? k_here : total_rows;
-    for (int64_t q = k_prev + 1; q <= hi; ++q) rowstart[q] = p;
+// rowstart for an edge-less build
+__global__ void k_rowstart_zero(int32_t total_rows, int32_t* __restrict__ rowstart) {
+  for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q <= total_rows; q += gridDim.x * blockDim.x) rowstart[q] = 0;
+}
+
+// vals[rowstart[key] + slot] = edge id; the counters return to zero
+__global__ void k_scatter(const uint32_t* __restrict__ keys, int32_t e_total, uint32_t sentinel,
+                          const int32_t* __restrict__ rowstart, uint32_t* __restrict__ cnt, uint32_t* __restrict__ vals) {
+  for (int32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < e_total; e += gridDim.x * blockDim.x) {
+    const uint32_t key = keys[e];
+    if (key >= sentinel) continue;
+    const uint32_t slot = atomicSub(cnt + key, 1u) - 1u;
+    vals[static_cast<uint32_t>(rowstart[key]) + slot] = static_cast<uint32_t>(e);
   }
 }
 
-__global__ void k_gather_col(SegTable t, const uint32_t* __restrict__ keys,
-                             const uint32_t* __restrict__ vals, int32_t* __restrict__ col,
-                             int32_t* __restrict__ perm) {
-  const int32_t e_total = t.ebase[t.n_seg];
-  const uint32_t sentinel = static_cast<uint32_t>(t.rbase[t.n_seg]);
-  for (int32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < e_total; p += gridDim.x * blockDim.x) {
-    if (keys[p] >= sentinel) {  // masked-out tail: defined but never referenced
-      col[p] = 0;
-      perm[p] = 0;
+constexpr int kSmallRow = 32;
+
+// one thread per row: rows of <= kSmallRow edges are sorted in place (insertion sort on ascending edge id = the
+// original order) and emitted; longer rows are appended to `heavy`
+__global__ void k_rows(SegTable t, const int32_t* __restrict__ rowstart, uint32_t* __restrict__ vals,
+                       int32_t* __restrict__ col, int32_t* __restrict__ perm, uint32_t* __restrict__ heavy_n,
+                       uint32_t* __restrict__ heavy) {
+  const int32_t r_total = t.rbase[t.n_seg];
+  for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < r_total; q += gridDim.x * blockDim.x) {
+    const int32_t s0 = rowstart[q], d = rowstart[q + 1] - s0;
+    if (d <= 0) continue;
+    if (d > kSmallRow) {
+      heavy[atomicAdd(heavy_n, 1u)] = static_cast<uint32_t>(q);
       continue;
     }
-    const int32_t e = static_cast<int32_t>(vals[p]);
-    const int s = find_seg(t, e);
-    const int32_t le = e - t.ebase[s];
-    col[p] = static_cast<int32_t>(t.col[s][le]);
-    perm[p] = le;
+    uint32_t* v = vals + s0;
+    for (int i = 1; i < d; ++i) {
+      const uint32_t x = v[i];
+      int j = i - 1;
+      while (j >= 0 && v[j] > x) { v[j + 1] = v[j]; --j; }
+      v[j + 1] = x;
+    }
+    int sg = 0;
+#pragma unroll 1
+    while (sg + 1 < t.n_seg && q >= t.rbase[sg + 1]) ++sg;
+    const int64_t* cs = t.col[sg];
+    const int32_t eb = t.ebase[sg];
+    for (int i = 0; i < d; ++i) {
+      const int32_t le = static_cast<int32_t>(v[i]) - eb;
+      col[s0 + i] = static_cast<int32_t>(cs[le]);
+      perm[s0 + i] = le;
+    }
+  }
+}
+
+// one wavefront per heavy row (rank sort), then the slots behind the kept edges are zero-filled
+__global__ __launch_bounds__(256) void k_heavy(SegTable t, const int32_t* __restrict__ rowstart, const uint32_t* __restrict__ vals,
+                                               int32_t* __restrict__ col, int32_t* __restrict__ perm,
+                                               const uint32_t* __restrict__ heavy_n, const uint32_t* __restrict__ heavy) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int n_waves = gridDim.x * (blockDim.x >> 6);
+  const uint32_t n_heavy = *heavy_n;
+  for (uint32_t h = wave; h < n_heavy; h += n_waves) {
+    const int32_t q = static_cast<int32_t>(heavy[h]);
+    const int32_t s0 = rowstart[q], d = rowstart[q + 1] - s0;
+    int sg = 0;
+#pragma unroll 1
+    while (sg + 1 < t.n_seg && q >= t.rbase[sg + 1]) ++sg;
+    const int64_t* cs = t.col[sg];
+    const int32_t eb = t.ebase[sg];
+    for (int32_t c0 = 0; c0 < d; c0 += 64) {
+      const bool mine = c0 + lane < d;
+      const uint32_t x = mine ? vals[s0 + c0 + lane] : 0xffffffffu;
+      int32_t rank = 0;
+      for (int32_t j0 = 0; j0 < d; j0 += 64) {
+        const uint32_t y = (j0 + lane < d) ? vals[s0 + j0 + lane] : 0xffffffffu;
+        const int m = (d - j0) < 64 ? (d - j0) : 64;
+        for (int b = 0; b < m; ++b) rank += (static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(y), b)) < x) ? 1 : 0;
+      }
+      if (mine) {                                   // edge ids are distinct: ranks are a permutation of 0 .. d-1
+        const int32_t le = static_cast<int32_t>(x) - eb;
+        col[s0 + rank] = static_cast<int32_t>(cs[le]);
+        perm[s0 + rank] = le;
+      }
+    }
+  }
+  const int32_t e_total = t.ebase[t.n_seg];
+  const int32_t kept = rowstart[t.rbase[t.n_seg]];
+  for (int32_t p = kept + blockIdx.x * blockDim.x + threadIdx.x; p < e_total; p += gridDim.x * blockDim.x) {
+    col[p] = 0;                                     // masked-out tail: defined but never referenced
+    perm[p] = 0;
   }
 }
 
@@ -87,28 +161,37 @@ __global__ void k_rowend(const int32_t* __restrict__ rowptr, const int32_t* __re
 
 inline size_t align_up(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 
-inline int bits_for(int64_t n) {  // number of key bits needed for values in [0, n]
-  int b = 1;
-  while ((int64_t{1} << b) <= n) ++b;
-  return b;
+size_t scan_temp_bytes(int64_t total_rows) {
+  size_t bytes = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, static_cast<const uint32_t*>(nullptr), static_cast<int32_t*>(nullptr),
+                                         static_cast<int>(total_rows + 1), nullptr);
+  return bytes;
 }
 
-size_t sort_temp_bytes(int64_t e_total, int64_t total_rows) {
-  size_t bytes = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, static_cast<const uint32_t*>(nullptr),
-                                     static_cast<uint32_t*>(nullptr),
-                                     static_cast<const uint32_t*>(nullptr),
-                                     static_cast<uint32_t*>(nullptr), static_cast<int>(e_total), 0,
-                                     bits_for(total_rows), nullptr);
-  return bytes;
+struct Layout {
+  size_t keys, vals, cnt, heavy, temp, temp_bytes, total;
+};
+
+Layout make_layout(int64_t e_total, int64_t total_rows) {
+  Layout l;
+  const size_t e = static_cast<size_t>(e_total > 0 ? e_total : 1), r = static_cast<size_t>(total_rows);
+  size_t off = 0;
+  l.keys = off; off += align_up(e * sizeof(uint32_t));
+  l.vals = off; off += align_up(e * sizeof(uint32_t));
+  l.cnt = off; off += align_up((r + 2) * sizeof(uint32_t));              // counters [total_rows + 1], then the heavy-row count
+  l.heavy = off; off += align_up((e / (kSmallRow + 1) + 1) * sizeof(uint32_t));
+  l.temp = off;
+  l.temp_bytes = scan_temp_bytes(total_rows);
+  off += align_up(l.temp_bytes);
+  l.total = off;
+  return l;
 }
 
 }  // namespace
 
 extern "C" size_t agnn_csr_workspace_bytes(int64_t e_total, int64_t total_rows) {
   if (e_total < 0 || total_rows < 0) return 0;
-  const size_t arr = align_up(static_cast<size_t>(e_total > 0 ? e_total : 1) * sizeof(uint32_t));
-  return 4 * arr + align_up(sort_temp_bytes(e_total > 0 ? e_total : 1, total_rows)) + 256;
+  return make_layout(e_total, total_rows).total + 256;
 }
 
 extern "C" int agnn_csr_build(int n_seg, const agnn_coo_seg_t* segs, int32_t* rowstart, int32_t* col,
@@ -141,36 +224,39 @@ extern "C" int agnn_csr_build(int n_seg, const agnn_coo_seg_t* segs, int32_t* ro
   const int threads = 256;
   if (e_total == 0) {
     const int blocks = static_cast<int>((r_total + 1 + threads - 1) / threads);
-    hipLaunchKernelGGL(k_rowstart, dim3(blocks), dim3(threads), 0, stream, nullptr, 0,
-                       static_cast<int32_t>(r_total), rowstart);
+    hipLaunchKernelGGL(k_rowstart_zero, dim3(blocks > 4096 ? 4096 : blocks), dim3(threads), 0, stream, static_cast<int32_t>(r_total), rowstart);
     return check_launch("csr_build/rowstart");
   }
   const size_t need = agnn_csr_workspace_bytes(e_total, r_total);
   if (!workspace || workspace_bytes < need) return fail(AGNN_ENOMEM, "csr_build: workspace %zu < %zu bytes", workspace_bytes, need);
-  const size_t arr = align_up(static_cast<size_t>(e_total) * sizeof(uint32_t));
-  char* ws = static_cast<char*>(workspace);
-  ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~uintptr_t{255});
-  uint32_t* keys_in = reinterpret_cast<uint32_t*>(ws);
-  uint32_t* keys_out = reinterpret_cast<uint32_t*>(ws + arr);
-  uint32_t* vals_in = reinterpret_cast<uint32_t*>(ws + 2 * arr);
-  uint32_t* vals_out = reinterpret_cast<uint32_t*>(ws + 3 * arr);
-  void* temp = ws + 4 * arr;
-  size_t temp_bytes = sort_temp_bytes(e_total, r_total);
+  const Layout l = make_layout(e_total, r_total);
+  char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t{255});
+  uint32_t* keys = reinterpret_cast<uint32_t*>(ws + l.keys);
+  uint32_t* vals = reinterpret_cast<uint32_t*>(ws + l.vals);
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(ws + l.cnt);
+  uint32_t* heavy_n = cnt + r_total + 1;
+  uint32_t* heavy = reinterpret_cast<uint32_t*>(ws + l.heavy);
+  void* temp = ws + l.temp;
+  size_t temp_bytes = l.temp_bytes;
 
+  hipError_t e = hipMemsetAsync(cnt, 0, static_cast<size_t>(r_total + 2) * sizeof(uint32_t), stream);
+  if (e != hipSuccess) return fail(AGNN_ERUNTIME, "csr_build/memset: %s", hipGetErrorString(e));
   int blocks = static_cast<int>((e_total + threads - 1) / threads);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_make_keys, dim3(blocks), dim3(threads), 0, stream, t, keys_in, vals_in);
-  if (int rc = check_launch("csr_build/make_keys")) return rc;
-  hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out,
-                                                    static_cast<int>(e_total), 0, bits_for(r_total), stream);
-  if (e != hipSuccess) return fail(AGNN_ERUNTIME, "csr_build/sort: %s", hipGetErrorString(e));
-  int blocks1 = static_cast<int>((e_total + 1 + threads - 1) / threads);
-  if (blocks1 > 4096) blocks1 = 4096;
-  hipLaunchKernelGGL(k_rowstart, dim3(blocks1), dim3(threads), 0, stream, keys_out,
-                     static_cast<int32_t>(e_total), static_cast<int32_t>(r_total), rowstart);
-  if (int rc = check_launch("csr_build/rowstart")) return rc;
-  hipLaunchKernelGGL(k_gather_col, dim3(blocks), dim3(threads), 0, stream, t, keys_out, vals_out, col, perm);
-  return check_launch("csr_build/gather_col");
+  hipLaunchKernelGGL(k_count, dim3(blocks), dim3(threads), 0, stream, t, keys, cnt);
+  if (int rc = check_launch("csr_build/count")) return rc;
+  e = hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, cnt, rowstart, static_cast<int>(r_total + 1), stream);
+  if (e != hipSuccess) return fail(AGNN_ERUNTIME, "csr_build/scan: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(threads), 0, stream, keys, static_cast<int32_t>(e_total),
+                     static_cast<uint32_t>(r_total), rowstart, cnt, vals);
+  if (int rc = check_launch("csr_build/scatter")) return rc;
+  int blocks_r = static_cast<int>((r_total + threads - 1) / threads);
+  if (blocks_r > 4096) blocks_r = 4096;
+  if (blocks_r < 1) blocks_r = 1;
+  hipLaunchKernelGGL(k_rows, dim3(blocks_r), dim3(threads), 0, stream, t, rowstart, vals, col, perm, heavy_n, heavy);
+  if (int rc = check_launch("csr_build/rows")) return rc;
+  hipLaunchKernelGGL(k_heavy, dim3(256), dim3(256), 0, stream, t, rowstart, vals, col, perm, heavy_n, heavy);
+  return check_launch("csr_build/heavy");
 }
 
 extern "C" int agnn_csr_rowend(const int32_t* rowptr, const int32_t* perm, int64_t n_rows, int64_t e_limit,

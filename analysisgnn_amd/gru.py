@@ -24,7 +24,8 @@ class _GRULayer(torch.autograd.Function):
         B, T, I = x.shape
         Hh = w_hh.shape[2]
         x2 = x.reshape(B * T, I)
-        gi = torch.addmm(b_ih.reshape(1, -1), x2, w_ih.reshape(6 * Hh, I).t())      # [B*T, 2*3H]
+        # 1-D bias: the library adds it in the GEMM epilogue (a [1, 6H] operand is first broadcast-copied into the 49 MB result)
+        gi = torch.addmm(b_ih.reshape(-1), x2, w_ih.reshape(6 * Hh, I).t())         # [B*T, 2*3H]
         w_hh_c = w_hh.contiguous()
         b_hh_c = b_hh.contiguous()
         y = torch.empty((B, T, 2 * Hh), dtype=torch.float32, device=dev)
