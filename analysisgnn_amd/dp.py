@@ -42,11 +42,42 @@ def shard_units(n_units: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_units, world))
 
 
-def _aligned_offsets(sizes: Sequence[int], align: int = 4) -> List[int]:
-    offs = [0]
-    for k in sizes:
-        offs.append(offs[-1] + (k + align - 1) // align * align)
+def _aligned_offsets(sizes: Sequence[int], align: int = 4, tight: Optional[Sequence[bool]] = None) -> List[int]:
+    """Start offset of every slot (+ the end): slots start on `align`-float boundaries, except that a slot marked `tight`
+    starts right where the previous one ends (members of a group that is consumed as one concatenated operand)."""
+    offs, end = [], 0
+    for i, k in enumerate(sizes):
+        start = end if (tight is not None and tight[i] and i > 0) else (end + align - 1) // align * align
+        offs.append(start)
+        end = start + k
+    offs.append((end + align - 1) // align * align)
     return offs
+
+
+def plan_parameters(model: torch.nn.Module):
+    """(params, tight): the trainable parameters in the order the flat buffers should hold them, and the ids of those that
+    must sit right behind their predecessor.  Modules may expose `adjacent_parameter_groups()` -> lists of parameters
+    that the hot path consumes concatenated (task-head layers, GRU direction pairs): laid out back to back, the cat /
+    stack is a view of the flat parameter buffer instead of a launch per step (params.cat_rows / stack_rows).  All other
+    parameters follow in `model.parameters()` order."""
+    groups = []
+    for m in model.modules():
+        fn = getattr(m, "adjacent_parameter_groups", None)
+        if fn is not None:
+            groups.extend([[p for p in g] for g in fn()])
+    seen, params, tight = set(), [], set()
+    for g in groups:
+        g = [p for p in g if p.requires_grad and id(p) not in seen]
+        for i, p in enumerate(g):
+            seen.add(id(p))
+            params.append(p)
+            if i > 0:
+                tight.add(id(p))
+    for p in model.parameters():
+        if p.requires_grad and id(p) not in seen:
+            seen.add(id(p))
+            params.append(p)
+    return params, tight
 
 
 class FlatGradBuffer:
@@ -60,14 +91,15 @@ class FlatGradBuffer:
         `.grad` then become views of the buffer so the optimizer sees the reduced / clipped values.
     """
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], views: bool = True):
+    def __init__(self, params: Iterable[torch.nn.Parameter], views: bool = True, tight: Optional[set] = None):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
         dev = self.params[0].device
         self.sizes = [p.numel() for p in self.params]
-        # every slot starts on a 16-byte boundary: the HIP kernels read parameters / gradients as float4
-        self.offsets = _aligned_offsets(self.sizes)
+        # every slot starts on a 16-byte boundary (the HIP kernels read parameters / gradients as float4), except the
+        # members of an adjacency group (plan_parameters), which are consumed through one view of the whole group
+        self.offsets = _aligned_offsets(self.sizes, tight=[tight is not None and id(p) in tight for p in self.params])
         n = self.offsets[-1]
         self.views = views
         for p in self.params:

@@ -125,7 +125,11 @@ def _stack_gru_params(rnn: nn.GRU):
         for n in names:
             flat.append(getattr(rnn, f"{n}_l{layer}"))
             flat.append(getattr(rnn, f"{n}_l{layer}_reverse"))
-    if flat[0].is_cuda and all(t.is_contiguous() and t.dtype == torch.float32 for t in flat):
+    from .params import adjacent, stack_rows
+    if all(adjacent(flat[i:i + 2]) for i in range(0, len(flat), 2)):      # laid out by dp.plan_parameters: views, no launch
+        outs = tuple(stack_rows(flat[i:i + 2]) for i in range(0, len(flat), 2))
+        leaves = all(t.is_leaf for t in flat)
+    elif flat[0].is_cuda and all(t.is_contiguous() and t.dtype == torch.float32 for t in flat):
         outs = _StackPairs.apply(*flat)
         leaves = all(t.is_leaf for t in flat)
     else:

@@ -22,6 +22,7 @@ import torch.nn.functional as F
 from . import _lib
 from .fused import grouped_norm_act
 from .linear import linear, mark_wgrad_async, wgrad_stream
+from .params import cat_rows, stack_rows
 
 
 def fused_head_logits(clf_dict: nn.ModuleDict, x: torch.Tensor, tasks: Sequence[str]) -> Tuple[torch.Tensor, List[int]]:
@@ -29,20 +30,21 @@ def fused_head_logits(clf_dict: nn.ModuleDict, x: torch.Tensor, tasks: Sequence[
     mods = [clf_dict[t] for t in tasks]
     T = len(mods)
     h2 = mods[0][0].out_features
-    # cat / stack of leaf parameters: their backward is narrow / unbind (views), so these gradients may arrive late
-    W1 = mark_wgrad_async(torch.cat([m[0].weight for m in mods], dim=0))  # [T*h2, o]
-    b1 = mark_wgrad_async(torch.cat([m[0].bias for m in mods], dim=0))
+    # cat / stack of leaf parameters: their backward is narrow / unbind (views), so these gradients may arrive late;
+    # the cats themselves are views when the parameters are adjacent in memory (dp.plan_parameters), launches otherwise
+    W1 = mark_wgrad_async(cat_rows([m[0].weight for m in mods]))          # [T*h2, o]
+    b1 = mark_wgrad_async(cat_rows([m[0].bias for m in mods]))
     a = linear(x, W1, b1)                                                 # [N, T*h2]
-    gamma = torch.stack([m[2].weight for m in mods])                      # [T, h2]
-    beta = torch.stack([m[2].bias for m in mods])
+    gamma = stack_rows([m[2].weight for m in mods])                       # [T, h2]
+    beta = stack_rows([m[2].bias for m in mods])
     a = grouped_norm_act(a.view(-1, T, h2), gamma, beta, mods[0][2].eps, pre_relu=True)   # ReLU + per-task LayerNorm, one launch
     offs = [0]
     for m in mods:
         offs.append(offs[-1] + m[3].out_features)
-    b2 = torch.cat([m[3].bias for m in mods], dim=0)
+    b2 = cat_rows([m[3].bias for m in mods])
     a = a.reshape(-1, T * h2)
     if a.is_cuda and h2 in GPROJ_K and T <= _lib.MAX_SEG and GPROJ_ENABLED:
-        W2 = mark_wgrad_async(torch.cat([m[3].weight for m in mods], dim=0))   # [sum C, h2]
+        W2 = mark_wgrad_async(cat_rows([m[3].weight for m in mods]))           # [sum C, h2]
         logits = grouped_projection(a, W2, mark_wgrad_async(b2), offs, h2)
     else:                                                                 # widths the kernel is not built for
         W2 = torch.block_diag(*[m[3].weight for m in mods])               # [sum C, T*h2]

@@ -79,6 +79,19 @@ class TorchAnalysisGNN(nn.Module):
             t: nn.Sequential(nn.Linear(o, o // 2), nn.ReLU(), nn.LayerNorm(o // 2), nn.Linear(o // 2, c))
             for t, c in task_dict.items()})
 
+    def adjacent_parameter_groups(self):
+        """Parameters the fused schedule consumes concatenated (heads.fused_head_logits: per-layer cats over the tasks;
+        gru._stack_gru_params: direction pairs): dp.plan_parameters lays them out back to back so that the cats are views."""
+        mods = list(self.clf_dict.values())
+        groups = [[m[0].weight for m in mods], [m[0].bias for m in mods], [m[2].weight for m in mods],
+                  [m[2].bias for m in mods], [m[3].weight for m in mods], [m[3].bias for m in mods]]
+        rnn = getattr(self.encoder, "rnn", None)
+        if isinstance(rnn, nn.GRU) and rnn.bidirectional:
+            for layer in range(rnn.num_layers):
+                for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                    groups.append([getattr(rnn, f"{n}_l{layer}"), getattr(rnn, f"{n}_l{layer}_reverse")])
+        return groups
+
     def encode(self, pitch_spelling, key_signature, x_dict, edge_index_dict, batch_dict, batch_size,
                neighbor_mask_node, neighbor_mask_edge):
         if self.training:

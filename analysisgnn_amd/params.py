@@ -90,3 +90,50 @@ def sage_operands(w_l: List[torch.Tensor], b_l: List[torch.Tensor], w_r: List[to
         for t in ops_:
             mark_wgrad_async(t)
     return ops_
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Parameters that sit side by side in memory (dp.FlatAdamW lays the model out in the order given by
+# dp.plan_parameters) are presented as ONE operand by a view — no launch at all; anywhere else `torch.cat`.
+# ------------------------------------------------------------------------------------------------------------
+def adjacent(ts: Sequence[torch.Tensor]) -> bool:
+    """True when the tensors are contiguous pieces of one storage, one right behind the other."""
+    t0 = ts[0]
+    if not all(t.is_contiguous() and t.dtype == t0.dtype and t.device == t0.device for t in ts):
+        return False
+    base = t0.untyped_storage().data_ptr()
+    off = t0.storage_offset()
+    for t in ts:
+        if t.untyped_storage().data_ptr() != base or t.storage_offset() != off:
+            return False
+        off += t.numel()
+    return True
+
+
+class _AdjacentCat(torch.autograd.Function):
+    """cat(params, dim=0) of adjacent parameters as a view of their common storage; backward = row slices (views)."""
+
+    @staticmethod
+    def forward(ctx, *params):
+        p0 = params[0]
+        rows = [int(p.shape[0]) for p in params]
+        ctx.rows = rows
+        return p0.detach().as_strided((sum(rows),) + tuple(p0.shape[1:]), p0.stride(), p0.storage_offset())
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g.split(ctx.rows, dim=0))
+
+
+def cat_rows(params: Sequence[torch.Tensor]) -> torch.Tensor:
+    """torch.cat(params, dim=0); free when the parameters are adjacent in memory."""
+    if len(params) > 1 and all(p.shape[1:] == params[0].shape[1:] for p in params) and adjacent(params):
+        return _AdjacentCat.apply(*params)
+    return torch.cat(list(params), dim=0)
+
+
+def stack_rows(params: Sequence[torch.Tensor]) -> torch.Tensor:
+    """torch.stack(params); free when the parameters are adjacent in memory."""
+    if len(params) > 1 and all(p.shape == params[0].shape for p in params) and adjacent(params):
+        return _AdjacentCat.apply(*[p.unsqueeze(0) for p in params])
+    return torch.stack(list(params))

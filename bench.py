@@ -143,11 +143,13 @@ def main():
     torch.manual_seed(0)                                            # identical replicas
     model = TorchAnalysisGNN(g.metadata(), IN_CH, hid, OUT, TASK_DICT, layers, dropout=0.3, use_jk=False,
                              encoder_type=enc).to(dev).train()
-    flat = dp.FlatGradBuffer(model.parameters(), views=False)
+    # parameters consumed concatenated (task-head layers, GRU direction pairs) sit back to back: their cats are views
+    params, tight = dp.plan_parameters(model)
+    flat = dp.FlatGradBuffer(params, views=False, tight=tight)
     # the GRU layers' weight-gradient work on its own stream, joined in flat.pack() — only where the sequence branch is
     # the longer one (C2; with HGT / MetricalGNN the graph branch is, and the extra stream only adds contention)
     dp.enable_wgrad_overlap(not args.no_wgrad_overlap and args.workload == "c2", "sequence")
-    opt = dp.FlatAdamW(model.parameters(), flat, lr=5e-3, weight_decay=5e-3)     # analysis.py:1380-1381 hyper-parameters
+    opt = dp.FlatAdamW(params, flat, lr=5e-3, weight_decay=5e-3)     # analysis.py:1380-1381 hyper-parameters
     graph.index_cache_enabled = False                               # fresh batch every step: rebuild the CSR
 
     from analysisgnn_amd.heads import multitask_cross_entropy

@@ -61,3 +61,55 @@ def test_graph_replay_equals_eager_step_and_is_reproducible():
     finally:
         dp.enable_wgrad_overlap(False)
         graph.index_cache_enabled = was
+
+
+def test_adjacent_parameter_layout_gives_the_same_step():
+    """dp.plan_parameters + FlatAdamW put the task-head layers and the GRU direction pairs back to back, so the fused
+    schedule reads them through views (params.cat_rows / stack_rows) instead of cat / pack launches: same loss and the same
+    gradient for every parameter as the model whose parameters live in separate allocations."""
+    from analysisgnn_amd import dp, graph
+    from analysisgnn_amd.heads import multitask_cross_entropy
+    from analysisgnn_amd.models import TorchAnalysisGNN
+    from analysisgnn_amd.params import adjacent
+    from analysisgnn_amd.synth import make_batch, torch_inputs
+    dev = torch.device("cuda", 0)
+    tasks = {"cadence": 4, "localkey": 50, "romanNumeral": 185, "hrythm": 2, "pcset": 94}
+    g = make_batch(4, 500)
+    I = torch_inputs(g, 25, dev, seed=0)
+    labels = torch.stack([torch.randint(0, c, (I["batch_size"],), generator=torch.Generator().manual_seed(i)).to(dev)
+                          for i, c in enumerate(tasks.values())])
+
+    def build():
+        torch.manual_seed(0)
+        return TorchAnalysisGNN(g.metadata(), 25, 256, 128, tasks, 3, dropout=0.0, use_jk=False).to(dev).train()
+
+    def step(model):
+        x = model.encode(I["pitch_spelling"], I["key_signature"], I["x_dict"], I["edge_index_dict"], I["batch_dict"],
+                         I["batch_size"], None, None)
+        logits, offs, _ = model.forward_clf_fused(x)
+        loss = 0.1 * x.pow(2).mean() + multitask_cross_entropy(logits, offs, labels, 0.1, -1).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss)
+
+    was = graph.index_cache_enabled
+    graph.index_cache_enabled = False
+    try:
+        a = build()
+        la = step(a)
+        b = build()
+        params, tight = dp.plan_parameters(b)
+        flat = dp.FlatGradBuffer(params, views=False, tight=tight)
+        dp.FlatAdamW(params, flat, lr=1e-3)
+        heads = list(b.clf_dict.values())
+        assert adjacent([m[0].weight for m in heads]) and adjacent([m[3].bias for m in heads])
+        assert adjacent([b.encoder.rnn.weight_hh_l1, b.encoder.rnn.weight_hh_l1_reverse])
+        assert not adjacent([m[3].bias for m in a.clf_dict.values()])
+        flat.zero()
+        lb = step(b)
+        assert la == lb
+        ga = dict(a.named_parameters())
+        for n, p in b.named_parameters():
+            assert p.grad is not None and torch.equal(p.grad, ga[n].grad), n
+    finally:
+        graph.index_cache_enabled = was
