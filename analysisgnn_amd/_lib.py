@@ -99,6 +99,13 @@ SIGNATURES = {
     "agnn_embed_workspace_bytes": (C.c_size_t, [C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
     "agnn_embed_cat_bwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_void_p),
                                          C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "agnn_train_loss_workspace_bytes": (C.c_size_t, []),
+    "agnn_train_loss_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_float, C.c_int64,
+                                      C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "agnn_train_loss_bwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_int64,
+                                          C.c_void_p]),
     "agnn_adamw_workspace_bytes": (C.c_size_t, []),
     "agnn_adamw_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float,
                                  C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t,

@@ -150,6 +150,101 @@ __global__ __launch_bounds__(256) void k_mtce_scale(const float* __restrict__ dz
   }
 }
 
+// Training loss in two launches:  total = sum_t loss[t] + lambda * mean(feat^2)
+// (ref: models/analysis.py:984 `feature_loss = x.pow(2).mean()`, :1072 `total_loss += ... feature_loss * self.lambda_featl`).
+// Blocks 0 .. T-1 reduce one task each (as k_mtce_reduce), blocks T .. T+kFeatBlocks-1 reduce a fixed slice of feat^2;
+// the last block to finish (integer ticket) adds the T + kFeatBlocks partial results in index order and resets the ticket:
+// the result does not depend on which block that was.
+constexpr int kFeatBlocks = 64;
+
+__global__ __launch_bounds__(1024) void k_train_loss_reduce(const float* __restrict__ row_loss, const int64_t* __restrict__ labels,
+                                                            int64_t n_rows, int64_t ignore, int T, float* __restrict__ loss,
+                                                            float* __restrict__ inv_cnt, const float* __restrict__ feat, int64_t ld_feat,
+                                                            int feat_cols, float lam_over_numel, float* __restrict__ fpart,
+                                                            unsigned int* __restrict__ ticket, float* __restrict__ total) {
+  __shared__ float sl[1024];
+  __shared__ int sc[1024];
+  __shared__ bool last;
+  const int t = blockIdx.x;
+  float a = 0.f;
+  int c = 0;
+  if (t < T) {
+    const float* rl = row_loss + static_cast<int64_t>(t) * n_rows;
+    const int64_t* lb = labels + static_cast<int64_t>(t) * n_rows;
+    for (int64_t i = threadIdx.x; i < n_rows; i += 1024) {
+      a += rl[i];
+      c += lb[i] != ignore ? 1 : 0;
+    }
+  } else if (feat != nullptr) {
+    const int64_t numel = n_rows * feat_cols;
+    const int64_t per = (numel + kFeatBlocks - 1) / kFeatBlocks;
+    const int64_t e0 = (t - T) * per;
+    int64_t e1 = e0 + per;
+    if (e1 > numel) e1 = numel;
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += 1024) {
+      const int64_t r = e / feat_cols;
+      const float v = feat[r * ld_feat + (e - r * feat_cols)];
+      a = fmaf(v, v, a);
+    }
+  }
+  sl[threadIdx.x] = a;
+  sc[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (static_cast<int>(threadIdx.x) < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (t < T) {
+      const float inv = 1.f / static_cast<float>(sc[0] > 0 ? sc[0] : 1);
+      loss[t] = sl[0] * inv;
+      inv_cnt[t] = inv;
+    } else {
+      fpart[t - T] = sl[0];
+    }
+    __threadfence();
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
+    __threadfence();
+    float tot = 0.f;
+    for (int i = 0; i < T; ++i) tot += __hip_atomic_load(loss + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float f = 0.f;
+    for (int i = 0; i < kFeatBlocks; ++i) f += __hip_atomic_load(fpart + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *total = fmaf(f, lam_over_numel, tot);
+    *ticket = 0u;
+  }
+}
+
+// Backward of the above in one launch: out[n, c] = dz[n, c] * g * inv_cnt[task(c)] (blocks over the logits rows), and
+// dfeat[n, c] = g * 2 * lambda / numel * feat[n, c] (the remaining blocks).
+__global__ __launch_bounds__(256) void k_train_loss_bwd(const float* __restrict__ dz, int64_t ld, const int32_t* __restrict__ off, int T,
+                                                        int64_t n_rows, int total_cols, const float* __restrict__ inv_cnt,
+                                                        const float* __restrict__ g, float* __restrict__ out, int64_t ld_out,
+                                                        const float* __restrict__ feat, int64_t ld_feat, int feat_cols, float coef,
+                                                        float* __restrict__ dfeat, int64_t ld_dfeat, unsigned logit_blocks) {
+  const int lane = threadIdx.x & 63;
+  const float gg = *g;
+  if (blockIdx.x < logit_blocks) {
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float* zr = dz + row * ld;
+    float* orow = out + row * ld_out;
+    const int lo = off[0], hi = off[T];
+    int t = 0;
+    for (int c = lane; c < total_cols; c += 64) {
+      while (t + 1 < T && c >= off[t + 1]) ++t;        // columns ascend per lane: the task index only moves forward
+      orow[c] = (c >= lo && c < hi) ? zr[c] * (gg * inv_cnt[t]) : 0.f;
+    }
+  } else {
+    const int64_t row = static_cast<int64_t>(blockIdx.x - logit_blocks) * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float s = gg * coef;
+    for (int c = lane; c < feat_cols; c += 64) dfeat[row * ld_dfeat + c] = s * feat[row * ld_feat + c];
+  }
+}
+
 }  // namespace
 
 extern "C" int agnn_multitask_ce_f32(const float* logits, int64_t ld, const int32_t* seg_off, int32_t n_tasks,
@@ -178,4 +273,45 @@ extern "C" int agnn_multitask_ce_scale_f32(const float* dlogits, int64_t ld, con
   hipLaunchKernelGGL(k_mtce_scale, dim3(static_cast<unsigned>((n_rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream_),
                      dlogits, ld, seg_off, n_tasks, n_rows, n_cols, scale, out, ld_out);
   return check_launch("multitask_ce_scale");
+}
+
+extern "C" size_t agnn_train_loss_workspace_bytes(void) { return 256 + kFeatBlocks * sizeof(float); }
+
+extern "C" int agnn_train_loss_f32(const float* logits, int64_t ld, const int32_t* seg_off, int32_t n_tasks, const int64_t* labels,
+                                   int64_t n_rows, float label_smoothing, int64_t ignore_index, const float* feat, int64_t ld_feat,
+                                   int32_t feat_cols, float lambda_feat, float* row_loss, float* dlogits, float* loss,
+                                   float* inv_count, float* total, void* workspace, size_t workspace_bytes, agnn_stream_t stream_) {
+  using namespace agnn;
+  if (n_rows <= 0 || n_tasks <= 0 || ld < 0) return fail(AGNN_EINVAL, "train_loss: n_rows=%lld n_tasks=%d", (long long)n_rows, n_tasks);
+  if (!logits || !seg_off || !labels || !row_loss || !dlogits || !loss || !inv_count || !total || !workspace) return fail(AGNN_EINVAL, "train_loss: null argument");
+  if (label_smoothing < 0.f || label_smoothing >= 1.f) return fail(AGNN_EINVAL, "train_loss: label_smoothing=%f", label_smoothing);
+  if (feat && (feat_cols <= 0 || ld_feat < feat_cols)) return fail(AGNN_EINVAL, "train_loss: feat_cols=%d ld_feat=%lld", feat_cols, (long long)ld_feat);
+  if (workspace_bytes < agnn_train_loss_workspace_bytes() || (reinterpret_cast<uintptr_t>(workspace) & 255u)) return fail(AGNN_ENOMEM, "train_loss: workspace too small or not 256-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  const unsigned blocks = static_cast<unsigned>((n_rows + 15) / 16);   // 4 waves x 4 rows
+  hipLaunchKernelGGL(k_mtce, dim3(blocks), dim3(256), 0, s, logits, ld, seg_off, n_tasks, labels, n_rows, label_smoothing,
+                     ignore_index, row_loss, dlogits);
+  if (int rc = check_launch("train_loss/ce")) return rc;
+  unsigned int* ticket = reinterpret_cast<unsigned int*>(workspace);
+  float* fpart = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + 256);
+  const float lam = feat ? lambda_feat / (static_cast<float>(n_rows) * static_cast<float>(feat_cols)) : 0.f;
+  hipLaunchKernelGGL(k_train_loss_reduce, dim3(n_tasks + kFeatBlocks), dim3(1024), 0, s, row_loss, labels, n_rows, ignore_index, n_tasks,
+                     loss, inv_count, feat, ld_feat, feat_cols, lam, fpart, ticket, total);
+  return check_launch("train_loss/reduce");
+}
+
+extern "C" int agnn_train_loss_bwd_f32(const float* dlogits, int64_t ld, const int32_t* seg_off, int32_t n_tasks, int64_t n_rows,
+                                       int32_t n_cols, const float* inv_count, const float* g, float* out, int64_t ld_out,
+                                       const float* feat, int64_t ld_feat, int32_t feat_cols, float lambda_feat, float* dfeat,
+                                       int64_t ld_dfeat, agnn_stream_t stream_) {
+  using namespace agnn;
+  if (n_rows <= 0 || n_tasks <= 0 || n_cols < 0 || n_cols > ld || n_cols > ld_out) return fail(AGNN_EINVAL, "train_loss_bwd: bad size");
+  if (!dlogits || !seg_off || !inv_count || !g || !out) return fail(AGNN_EINVAL, "train_loss_bwd: null argument");
+  if (dfeat && (!feat || feat_cols <= 0 || ld_feat < feat_cols || ld_dfeat < feat_cols)) return fail(AGNN_EINVAL, "train_loss_bwd: bad feature arguments");
+  const unsigned lb = static_cast<unsigned>((n_rows + 3) / 4);
+  const unsigned fb = dfeat ? lb : 0u;
+  const float coef = dfeat ? 2.f * lambda_feat / (static_cast<float>(n_rows) * static_cast<float>(feat_cols)) : 0.f;
+  hipLaunchKernelGGL(k_train_loss_bwd, dim3(lb + fb), dim3(256), 0, static_cast<hipStream_t>(stream_), dlogits, ld, seg_off, n_tasks, n_rows,
+                     n_cols, inv_count, g, out, ld_out, feat, ld_feat, feat_cols, coef, dfeat, ld_dfeat, lb);
+  return check_launch("train_loss_bwd");
 }

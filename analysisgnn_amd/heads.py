@@ -164,3 +164,68 @@ def multitask_cross_entropy(logits: torch.Tensor, offs: Sequence[int], labels: t
 
 
 _OFFS_CACHE: Dict[tuple, torch.Tensor] = {}
+_LOSS_WS: Dict[str, torch.Tensor] = {}
+
+
+class _TrainLoss(torch.autograd.Function):
+    """total = sum_t CE_t + lam * mean(feat^2) (agnn_train_loss_f32: two launches) and its gradient w.r.t. the logits and
+    feat (agnn_train_loss_bwd_f32: one launch)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, offs_t, feat, eps: float, ignore_index: int, lam: float):
+        dev = _lib.require_gpu(logits, labels, offs_t, feat)
+        if logits.dtype != torch.float32 or logits.stride(1) != 1:
+            logits = logits.float().contiguous()
+        if feat.dtype != torch.float32 or feat.stride(1) != 1:
+            feat = feat.float().contiguous()
+        N = logits.shape[0]
+        T = offs_t.numel() - 1
+        labels = labels.contiguous()
+        lib = _lib.load()
+        ws = _LOSS_WS.get(str(dev))
+        if ws is None:                                        # zero-filled once; every call leaves it zero-filled
+            ws = _LOSS_WS[str(dev)] = torch.zeros(int(lib.agnn_train_loss_workspace_bytes()) + 256, dtype=torch.uint8, device=dev)
+        wsp = (ws.data_ptr() + 255) & ~255
+        row_loss = torch.empty((T, N), dtype=torch.float32, device=dev)
+        out = torch.empty((2 * T + 1,), dtype=torch.float32, device=dev)      # loss[T] | inv_cnt[T] | total
+        dlogits = torch.empty_like(logits)
+        _lib.check(lib.agnn_train_loss_f32(logits.data_ptr(), logits.stride(0), offs_t.data_ptr(), T, labels.data_ptr(), N, float(eps),
+                                           int(ignore_index), feat.data_ptr(), feat.stride(0), feat.shape[1], float(lam),
+                                           row_loss.data_ptr(), dlogits.data_ptr(), out.data_ptr(), out[T:].data_ptr(),
+                                           out[2 * T:].data_ptr(), wsp, int(lib.agnn_train_loss_workspace_bytes()),
+                                           _lib.stream_ptr(dev)), "agnn_train_loss_f32")
+        ctx.save_for_backward(dlogits, offs_t, out, feat)
+        ctx.lam = float(lam)
+        ctx.mark_non_differentiable(out)
+        return out[2 * T], out
+
+    @staticmethod
+    def backward(ctx, g, _g_parts):
+        dlogits, offs_t, out, feat = ctx.saved_tensors
+        dev = dlogits.device
+        T = offs_t.numel() - 1
+        g = g.to(torch.float32).contiguous()
+        dl = torch.empty_like(dlogits)
+        dfeat = torch.empty_like(feat) if ctx.needs_input_grad[3] else None
+        lib = _lib.load()
+        _lib.check(lib.agnn_train_loss_bwd_f32(dlogits.data_ptr(), dlogits.stride(0), offs_t.data_ptr(), T, dlogits.shape[0],
+                                               dlogits.shape[1], out[T:].data_ptr(), g.data_ptr(), dl.data_ptr(), dl.stride(0),
+                                               feat.data_ptr(), feat.stride(0), feat.shape[1], ctx.lam, _lib.ptr(dfeat),
+                                               dfeat.stride(0) if dfeat is not None else 0, _lib.stream_ptr(dev)),
+                   "agnn_train_loss_bwd_f32")
+        return dl, None, None, dfeat, None, None, None
+
+
+def training_loss(logits: torch.Tensor, offs: Sequence[int], labels: torch.Tensor, feat: torch.Tensor, lambda_feat: float = 0.1,
+                  label_smoothing: float = 0.1, ignore_index: int = -1) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(total, per_task) with total = sum_t CrossEntropy_t + lambda_feat * feat.pow(2).mean() — the reference's training
+    objective without its optional terms (models/analysis.py:881-888, :984, :1072) — in two launches forward and one
+    backward.  per_task [T] are the mean losses per task (for logging; not differentiable).  Requires segments that
+    cover the logits' columns side by side (what fused_head_logits produces)."""
+    full = len(offs) > 1 and offs[0] == 0 and offs[-1] == logits.shape[1] and all(offs[i] < offs[i + 1] for i in range(len(offs) - 1))
+    if not full:
+        per_task = multitask_cross_entropy(logits, offs, labels, label_smoothing, ignore_index)
+        return per_task.sum() + lambda_feat * feat.pow(2).mean(), per_task.detach()
+    total, out = _TrainLoss.apply(logits, labels, _offs_tensor(offs, logits.device), feat, label_smoothing, ignore_index, lambda_feat)
+    return total, out[:len(offs) - 1]
+

@@ -152,7 +152,7 @@ def main():
     opt = dp.FlatAdamW(params, flat, lr=5e-3, weight_decay=5e-3)     # analysis.py:1380-1381 hyper-parameters
     graph.index_cache_enabled = False                               # fresh batch every step: rebuild the CSR
 
-    from analysisgnn_amd.heads import multitask_cross_entropy
+    from analysisgnn_amd.heads import training_loss
     label_mat = torch.stack([labels[t] for t in TASK_DICT])             # [T, N]
 
     def fwd_bwd():
@@ -160,7 +160,7 @@ def main():
         x = model.encode(I["pitch_spelling"], I["key_signature"], I["x_dict"], I["edge_index_dict"], I["batch_dict"],
                          I["batch_size"], None, None)
         logits, offs, _ = model.forward_clf_fused(x)
-        loss = 0.1 * x.pow(2).mean() + multitask_cross_entropy(logits, offs, label_mat, 0.1, -1).sum()
+        loss, _ = training_loss(logits, offs, label_mat, x, 0.1, 0.1, -1)      # sum_t CE_t + 0.1 * x.pow(2).mean(), analysis.py:1072
         loss.backward()
         flat.pack()
         return loss

@@ -334,6 +334,28 @@ int agnn_multitask_ce_scale_f32(const float* dlogits, int64_t ld, const int32_t*
                                 agnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training loss of one step in two launches, its gradient in one:
+ *     total = sum_t loss[t] + lambda_feat * mean(feat^2)
+ * i.e. the per-task label-smoothed cross entropies above plus the reference's feature-norm term
+ * (ref: models/analysis.py:984 `feature_loss = x.pow(2).mean()`, :1072 `... + feature_loss * self.lambda_featl`, :910
+ * default 0.1).  Same per-task outputs as agnn_multitask_ce_f32, plus `total` (device scalar).  feat [n_rows, feat_cols]
+ * (ld_feat) may be NULL (no feature term).  `workspace` (agnn_train_loss_workspace_bytes(), 256-byte aligned) must be
+ * ZERO-FILLED before its first use; every call leaves it zero-filled again (it holds the ticket of the fixed-order final
+ * sum).  Backward, given g = d(objective)/d(total) as a DEVICE scalar:
+ *     out[n, c]   = dlogits[n, c] * g * inv_count[task(c)]          (columns outside the segments: 0)
+ *     dfeat[n, c] = g * 2 * lambda_feat / (n_rows * feat_cols) * feat[n, c]        (dfeat NULL to skip)
+ * ------------------------------------------------------------------------------------------ */
+size_t agnn_train_loss_workspace_bytes(void);
+int agnn_train_loss_f32(const float* logits, int64_t ld, const int32_t* seg_off, int32_t n_tasks, const int64_t* labels,
+                        int64_t n_rows, float label_smoothing, int64_t ignore_index, const float* feat, int64_t ld_feat,
+                        int32_t feat_cols, float lambda_feat, float* row_loss, float* dlogits, float* loss,
+                        float* inv_count, float* total, void* workspace, size_t workspace_bytes, agnn_stream_t stream);
+int agnn_train_loss_bwd_f32(const float* dlogits, int64_t ld, const int32_t* seg_off, int32_t n_tasks, int64_t n_rows,
+                            int32_t n_cols, const float* inv_count, const float* g, float* out, int64_t ld_out,
+                            const float* feat, int64_t ld_feat, int32_t feat_cols, float lambda_feat, float* dfeat,
+                            int64_t ld_dfeat, agnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Global-norm gradient clipping + AdamW over flat fp32 buffers (ref optimizer: models/analysis.py:1380-1381
  * `torch.optim.AdamW`; clipping as Lightning's gradient_clip_val does before the step):
  *     g' = g * min(max_norm / (||g||_2 + 1e-6), 1)            (max_norm <= 0: no clipping)

@@ -98,3 +98,39 @@ def test_grouped_projection_matches_per_task_linear(K, classes, N):
     assert_close(ag.grad, a64.grad.float(), 1e-5, "da")
     assert_close(wg.grad, w64.grad.float(), 1e-5, "dw")
     assert_close(bg.grad, b64.grad.float(), 1e-5, "db")
+
+
+@pytest.mark.parametrize("N,lam,gscale", [(301, 0.1, 1.0), (16000, 0.1, 1.0), (37, 0.5, 3.0)])
+def test_training_loss_matches_torch(N, lam, gscale):
+    """heads.training_loss (agnn_train_loss_f32 / _bwd_f32) = sum_t CE_t + lam * feat.pow(2).mean() (analysis.py:881-888, :984,
+    :1072) against F.cross_entropy on the CPU; tolerance 1e-4 relative (fp32 sums in a different order).  Called twice:
+    the ticket workspace must be left clean, and the result must be bitwise reproducible."""
+    from analysisgnn_amd.heads import training_loss
+    g = torch.Generator().manual_seed(N)
+    C = list(TASKS.values())
+    offs = [0]
+    for c in C:
+        offs.append(offs[-1] + c)
+    logits = torch.randn(N, offs[-1], generator=g) * 2
+    feat = torch.randn(N, 128, generator=g)
+    labels = torch.stack([torch.randint(0, c, (N,), generator=g) for c in C])
+    labels[1, ::5] = -1
+    labels[3, :] = -1                                    # a task with no valid row
+    lr, fr = logits.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    per = torch.stack([torch.nan_to_num(F.cross_entropy(lr[:, offs[i]:offs[i + 1]], labels[i], ignore_index=-1, label_smoothing=0.1), nan=0.0)
+                       for i in range(len(C))])
+    ref = per.sum() + lam * fr.pow(2).mean()
+    (ref * gscale).backward()
+    lg, fg = logits.to(DEV).requires_grad_(True), feat.to(DEV).requires_grad_(True)
+    outs = []
+    for _ in range(2):
+        lg.grad = fg.grad = None
+        total, per_task = training_loss(lg, offs, labels.to(DEV), fg, lam, 0.1, -1)
+        (total * gscale).backward()
+        outs.append((total.detach().clone(), lg.grad.clone(), fg.grad.clone()))
+    assert_close(outs[0][0], ref.detach(), 1e-4, "total")
+    assert_close(per_task, per.detach(), 1e-4, "per-task losses")
+    assert_close(outs[0][1], lr.grad, 1e-4, "dlogits")
+    assert_close(outs[0][2], fr.grad, 1e-4, "dfeat")
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
