@@ -181,10 +181,17 @@ __global__ __launch_bounds__(1024) void k_train_loss_reduce(const float* __restr
     const int64_t e0 = (t - T) * per;
     int64_t e1 = e0 + per;
     if (e1 > numel) e1 = numel;
-    for (int64_t e = e0 + threadIdx.x; e < e1; e += 1024) {
-      const int64_t r = e / feat_cols;
-      const float v = feat[r * ld_feat + (e - r * feat_cols)];
-      a = fmaf(v, v, a);
+    if (ld_feat == feat_cols) {                       // contiguous: no index arithmetic
+      for (int64_t e = e0 + threadIdx.x; e < e1; e += 1024) {
+        const float v = feat[e];
+        a = fmaf(v, v, a);
+      }
+    } else {
+      for (int64_t e = e0 + threadIdx.x; e < e1; e += 1024) {
+        const int64_t r = e / feat_cols;
+        const float v = feat[r * ld_feat + (e - r * feat_cols)];
+        a = fmaf(v, v, a);
+      }
     }
   }
   sl[threadIdx.x] = a;

@@ -197,6 +197,7 @@ class _TrainLoss(torch.autograd.Function):
         ctx.save_for_backward(dlogits, offs_t, out, feat)
         ctx.lam = float(lam)
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)                      # no zero-filled gradient for the logging output
         return out[2 * T], out
 
     @staticmethod
