@@ -226,29 +226,62 @@ __global__ __launch_bounds__(1024) void k_train_loss_reduce(const float* __restr
 
 // Backward of the above in one launch: out[n, c] = dz[n, c] * g * inv_cnt[task(c)] (blocks over the logits rows), and
 // dfeat[n, c] = g * 2 * lambda / numel * feat[n, c] (the remaining blocks).
+constexpr int kBwdMaxCols = 4096;                     // per-column scale table in LDS (16 KB)
+
+template <int VEC>      // floats per access on the logits rows: 4, 2 or 0 (scalar, any layout)
 __global__ __launch_bounds__(256) void k_train_loss_bwd(const float* __restrict__ dz, int64_t ld, const int32_t* __restrict__ off, int T,
                                                         int64_t n_rows, int total_cols, const float* __restrict__ inv_cnt,
                                                         const float* __restrict__ g, float* __restrict__ out, int64_t ld_out,
                                                         const float* __restrict__ feat, int64_t ld_feat, int feat_cols, float coef,
                                                         float* __restrict__ dfeat, int64_t ld_dfeat, unsigned logit_blocks) {
+  __shared__ __attribute__((aligned(16))) float s_scale[VEC ? kBwdMaxCols : 1];
   const int lane = threadIdx.x & 63;
   const float gg = *g;
   if (blockIdx.x < logit_blocks) {
-    const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
-    if (row >= n_rows) return;
-    const float* zr = dz + row * ld;
-    float* orow = out + row * ld_out;
-    const int lo = off[0], hi = off[T];
-    int t = 0;
-    for (int c = lane; c < total_cols; c += 64) {
-      while (t + 1 < T && c >= off[t + 1]) ++t;        // columns ascend per lane: the task index only moves forward
-      orow[c] = (c >= lo && c < hi) ? zr[c] * (gg * inv_cnt[t]) : 0.f;
+    if (VEC) {                                        // column -> g / count of its task, once per block; rows as float4
+      const int lo = off[0], hi = off[T];
+      for (int c = threadIdx.x; c < total_cols; c += 256) {
+        int t = 0;
+        while (t + 1 < T && c >= off[t + 1]) ++t;
+        s_scale[c] = (c >= lo && c < hi) ? gg * inv_cnt[t] : 0.f;
+      }
+      __syncthreads();
+      for (int64_t row = static_cast<int64_t>(blockIdx.x) * 16 + (threadIdx.x >> 6); row < n_rows && row < static_cast<int64_t>(blockIdx.x + 1) * 16; row += 4) {
+        if (VEC == 4) {
+          const float4* zr = reinterpret_cast<const float4*>(dz + row * ld);
+          float4* orow = reinterpret_cast<float4*>(out + row * ld_out);
+          for (int c = lane; c < (total_cols >> 2); c += 64) {
+            const float4 v = zr[c];
+            const float4 sc = *reinterpret_cast<const float4*>(&s_scale[4 * c]);
+            orow[c] = make_float4(v.x * sc.x, v.y * sc.y, v.z * sc.z, v.w * sc.w);
+          }
+        } else {
+          const float2* zr = reinterpret_cast<const float2*>(dz + row * ld);
+          float2* orow = reinterpret_cast<float2*>(out + row * ld_out);
+          for (int c = lane; c < (total_cols >> 1); c += 64) {
+            const float2 v = zr[c];
+            const float2 sc = *reinterpret_cast<const float2*>(&s_scale[2 * c]);
+            orow[c] = make_float2(v.x * sc.x, v.y * sc.y);
+          }
+        }
+      }
+    } else {
+      for (int64_t row = static_cast<int64_t>(blockIdx.x) * 16 + (threadIdx.x >> 6); row < n_rows && row < static_cast<int64_t>(blockIdx.x + 1) * 16; row += 4) {
+        const float* zr = dz + row * ld;
+        float* orow = out + row * ld_out;
+        const int lo = off[0], hi = off[T];
+        int t = 0;
+        for (int c = lane; c < total_cols; c += 64) {
+          while (t + 1 < T && c >= off[t + 1]) ++t;    // columns ascend per lane: the task index only moves forward
+          orow[c] = (c >= lo && c < hi) ? zr[c] * (gg * inv_cnt[t]) : 0.f;
+        }
+      }
     }
   } else {
-    const int64_t row = static_cast<int64_t>(blockIdx.x - logit_blocks) * 4 + (threadIdx.x >> 6);
-    if (row >= n_rows) return;
     const float s = gg * coef;
-    for (int c = lane; c < feat_cols; c += 64) dfeat[row * ld_dfeat + c] = s * feat[row * ld_feat + c];
+    const int64_t b = blockIdx.x - logit_blocks;
+    for (int64_t row = b * 16 + (threadIdx.x >> 6); row < n_rows && row < (b + 1) * 16; row += 4)
+      for (int c = lane; c < feat_cols; c += 64) dfeat[row * ld_dfeat + c] = s * feat[row * ld_feat + c];
   }
 }
 
@@ -315,10 +348,17 @@ extern "C" int agnn_train_loss_bwd_f32(const float* dlogits, int64_t ld, const i
   if (n_rows <= 0 || n_tasks <= 0 || n_cols < 0 || n_cols > ld || n_cols > ld_out) return fail(AGNN_EINVAL, "train_loss_bwd: bad size");
   if (!dlogits || !seg_off || !inv_count || !g || !out) return fail(AGNN_EINVAL, "train_loss_bwd: null argument");
   if (dfeat && (!feat || feat_cols <= 0 || ld_feat < feat_cols || ld_dfeat < feat_cols)) return fail(AGNN_EINVAL, "train_loss_bwd: bad feature arguments");
-  const unsigned lb = static_cast<unsigned>((n_rows + 3) / 4);
+  const unsigned lb = static_cast<unsigned>((n_rows + 15) / 16);      // 16 rows per workgroup
   const unsigned fb = dfeat ? lb : 0u;
   const float coef = dfeat ? 2.f * lambda_feat / (static_cast<float>(n_rows) * static_cast<float>(feat_cols)) : 0.f;
-  hipLaunchKernelGGL(k_train_loss_bwd, dim3(lb + fb), dim3(256), 0, static_cast<hipStream_t>(stream_), dlogits, ld, seg_off, n_tasks, n_rows,
-                     n_cols, inv_count, g, out, ld_out, feat, ld_feat, feat_cols, coef, dfeat, ld_dfeat, lb);
+  const uintptr_t al = reinterpret_cast<uintptr_t>(dlogits) | reinterpret_cast<uintptr_t>(out);
+  const int64_t geo = n_cols | ld | ld_out;
+  const int vec = n_cols > kBwdMaxCols ? 0 : ((geo & 3) == 0 && (al & 15u) == 0 ? 4 : ((geo & 1) == 0 && (al & 7u) == 0 ? 2 : 0));
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+#define AGNN_TLB(V)                                                                                                              \
+  hipLaunchKernelGGL(k_train_loss_bwd<V>, dim3(lb + fb), dim3(256), 0, s, dlogits, ld, seg_off, n_tasks, n_rows, n_cols, inv_count, \
+                     g, out, ld_out, feat, ld_feat, feat_cols, coef, dfeat, ld_dfeat, lb)
+  if (vec == 4) AGNN_TLB(4); else if (vec == 2) AGNN_TLB(2); else AGNN_TLB(0);
+#undef AGNN_TLB
   return check_launch("train_loss_bwd");
 }

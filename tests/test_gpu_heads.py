@@ -100,14 +100,15 @@ def test_grouped_projection_matches_per_task_linear(K, classes, N):
     assert_close(bg.grad, b64.grad.float(), 1e-5, "db")
 
 
+@pytest.mark.parametrize("extra", [(), (5,), (3,)])      # 335 logit columns (scalar rows) / 340 (float4 backward) / 338 (float2)
 @pytest.mark.parametrize("N,lam,gscale", [(301, 0.1, 1.0), (16000, 0.1, 1.0), (37, 0.5, 3.0)])
-def test_training_loss_matches_torch(N, lam, gscale):
+def test_training_loss_matches_torch(N, lam, gscale, extra):
     """heads.training_loss (agnn_train_loss_f32 / _bwd_f32) = sum_t CE_t + lam * feat.pow(2).mean() (analysis.py:881-888, :984,
     :1072) against F.cross_entropy on the CPU; tolerance 1e-4 relative (fp32 sums in a different order).  Called twice:
     the ticket workspace must be left clean, and the result must be bitwise reproducible."""
     from analysisgnn_amd.heads import training_loss
     g = torch.Generator().manual_seed(N)
-    C = list(TASKS.values())
+    C = list(TASKS.values()) + list(extra)
     offs = [0]
     for c in C:
         offs.append(offs[-1] + c)
