@@ -272,8 +272,8 @@ def main():
                          "achieved": b_alg / t_fwd / 1e9 if t_fwd > 0 else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": (b_alg / t_fwd) / HBM_PEAK if t_fwd > 0 else None,
                          # HBM bytes per launch from rocprofv3 PMC passes of this kernel at this shape (FETCH_SIZE x2 gfx950
-                         # correction + WRITE_SIZE, separate passes): profiles/r01_spmm_kernel_study.md — not re-collected per run
-                         "traffic": 83.5e6 if args.workload == "c2" else None,
+                         # correction + WRITE_SIZE, separate passes): profiles/r01_spmm_kernel_study.md part 2 — not re-collected per run
+                         "traffic": 83.2e6 if args.workload == "c2" else None,
                          "alg_bytes_per_launch": b_alg, "avg_us": t_fwd * 1e6, "launches": len(fwd) * REP, "timing": "HIP events around hipGraph replays of 10 back-to-back launches"},
         }
         if world == 1 and not args.no_cpu_baseline:
