@@ -94,6 +94,8 @@ SIGNATURES = {
     "agnn_gproj_bwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_void_p]),
+    "agnn_spmm_self_grad_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
+                                          C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "agnn_embed_cat_fwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_void_p),
                                          C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "agnn_embed_workspace_bytes": (C.c_size_t, [C.c_int32, C.POINTER(C.c_int32), C.c_int32]),

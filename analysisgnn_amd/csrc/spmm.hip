@@ -612,6 +612,44 @@ void launch_s(dim3 grid, hipStream_t stream, const RelTable& t, const SpmmArgs& 
 
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void k_spmm_self_grad(const float* __restrict__ dout, int64_t ld_dout, int64_t rel_stride, int n_rel,
+                                                        const float* __restrict__ inv_cnt, int64_t ld_inv, int64_t n_rows, int H4,
+                                                        float* __restrict__ out, int64_t ld_out, int accumulate) {
+  const int64_t total = n_rows * H4;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t i = e / H4;
+    const int c = static_cast<int>(e - i * H4) * 4;
+    float4 acc = f4_zero();
+    for (int r = 0; r < n_rel; ++r) {
+      const float w = inv_cnt != nullptr ? inv_cnt[r * ld_inv + i] : 1.f;
+      f4_fma(acc, w, *reinterpret_cast<const float4*>(dout + i * ld_dout + r * rel_stride + c));
+    }
+    float4* q = reinterpret_cast<float4*>(out + i * ld_out + c);
+    if (accumulate) f4_add(acc, *q);
+    *q = acc;
+  }
+}
+}  // namespace
+
+extern "C" int agnn_spmm_self_grad_f32(const float* dout, int64_t ld_dout, int64_t rel_stride, int32_t n_rel, const float* inv_cnt,
+                                       int64_t ld_inv, int64_t n_rows, int32_t H, float* out, int64_t ld_out, int32_t accumulate,
+                                       agnn_stream_t stream_) {
+  using namespace agnn;
+  if (n_rel <= 0 || n_rows < 0 || H <= 0 || (H & 3)) return fail(AGNN_EINVAL, "spmm_self_grad: n_rel=%d n_rows=%lld H=%d (H must be a multiple of 4)", n_rel, (long long)n_rows, H);
+  if (n_rows == 0) return AGNN_OK;
+  if (!dout || !out) return fail(AGNN_EINVAL, "spmm_self_grad: null argument");
+  if (!aligned16(dout) || !aligned16(out) || (ld_dout & 3) || (ld_out & 3) || (rel_stride & 3) || ld_out < H || ld_dout < H)
+    return fail(AGNN_EALIGN, "spmm_self_grad: operands must be 16-byte aligned with leading dimensions >= H");
+  if (inv_cnt && ld_inv < n_rows) return fail(AGNN_EINVAL, "spmm_self_grad: ld_inv=%lld < n_rows", (long long)ld_inv);
+  const int64_t total = n_rows * (H / 4);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_spmm_self_grad, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream_), dout, ld_dout,
+                     rel_stride, n_rel, inv_cnt, ld_inv, n_rows, H / 4, out, ld_out, accumulate);
+  return check_launch("spmm_self_grad");
+}
+
 extern "C" int agnn_spmm_f32(int n_rel, const agnn_rel_t* rels, int64_t n_rows, int32_t H, float* out,
                              int64_t ld_out, int64_t rel_stride, const float* self, int64_t ld_self,
                              float* inv_cnt, int32_t col_limit, uint32_t flags, agnn_stream_t stream_) {

@@ -119,6 +119,13 @@ class _Aggregate(torch.autograd.Function):
         ctx.src_rows = [s.shape[0] for s in srcs]
         ctx.has_self = self_t is not None
         ctx.self_rows = self_t.shape[0] if self_t is not None else 0
+        # `self` and a source are the same matrix (onset pooling): its two gradients are produced as one
+        ctx.self_src = -1
+        if self_t is not None:
+            for k, s_ in enumerate(srcs):
+                if s_.data_ptr() == self_t.data_ptr() and s_.shape == self_t.shape and s_.stride() == self_t.stride():
+                    ctx.self_src = k
+                    break
         ctx.save_for_backward(*( [inv_cnt] if inv_cnt is not None else [] ))
         return out
 
@@ -167,17 +174,23 @@ class _Aggregate(torch.autograd.Function):
                 _launch(rels, rows_t, H, g, 0, None, None, lim, flags, tag="bwd")
             grads.append(g)
         gself = None
-        if ctx.has_self and ctx.needs_input_grad[1]:
-            if spec.shared_slot:
-                gs = dout * inv_cnt.sum(dim=0)[:n].unsqueeze(-1) if spec.mean else dout * float(R)
+        if ctx.has_self and ctx.needs_input_grad[1] and n > 0:
+            # d/d self = sum_r dout_r * (1/cnt_r | 1): one launch (agnn_spmm_self_grad_f32), added straight onto the source's
+            # gradient when self and that source are one matrix (autograd would otherwise add the two with another launch)
+            lib = _lib.load()
+            k = ctx.self_src
+            fold = k >= 0 and grads[k] is not None
+            if fold:
+                tgt, acc = grads[k], 1
             else:
-                d3 = dout.view(n, R, H)
-                gs = (d3 * inv_cnt[:, :n].t().unsqueeze(-1)).sum(dim=1) if spec.mean else d3.sum(dim=1)
-            if ctx.self_rows > n:
-                gself = torch.zeros((ctx.self_rows, H), dtype=torch.float32, device=dev)
-                gself[:n] = gs
-            else:
-                gself = gs
+                tgt = (torch.zeros if ctx.self_rows > n else torch.empty)((ctx.self_rows, H), dtype=torch.float32, device=dev)
+                acc = 0
+            _lib.check(lib.agnn_spmm_self_grad_f32(dout.data_ptr(), dout.stride(0), 0 if spec.shared_slot else H, R, _lib.ptr(inv_cnt),
+                                                   inv_cnt.stride(0) if inv_cnt is not None else 0, n, H, tgt.data_ptr(), tgt.stride(0),
+                                                   acc, _lib.stream_ptr(dev)), "agnn_spmm_self_grad_f32")
+            gself = None if fold else tgt
+        elif ctx.has_self and ctx.needs_input_grad[1]:
+            gself = torch.zeros((ctx.self_rows, H), dtype=torch.float32, device=dev)
         return (None, gself, *grads)
 
 

@@ -131,6 +131,15 @@ int agnn_spmm_f32(int n_rel, const agnn_rel_t* rels /* (host) */, int64_t n_rows
                   const float* self, int64_t ld_self,
                   float* inv_cnt, int32_t col_limit, uint32_t flags, agnn_stream_t stream);
 
+/* Gradient of agnn_spmm_f32 w.r.t. its `self` operand, optionally added onto an existing gradient:
+ *     out[i, 0:H] (=|+=) sum_{r < n_rel} dout[i*ld_dout + r*rel_stride + 0:H] * (inv_cnt ? inv_cnt[r*ld_inv + i] : 1)
+ * (rel_stride == 0: every relation read the same slot).  One launch instead of the reduce / multiply / add chain; with
+ * `accumulate` it lands on the neighbour gradient the backward SpMM has just written when `self` and the source are the
+ * same matrix (onset pooling, ref: models/analysis.py:580-587). */
+int agnn_spmm_self_grad_f32(const float* dout, int64_t ld_dout, int64_t rel_stride, int32_t n_rel, const float* inv_cnt,
+                            int64_t ld_inv, int64_t n_rows, int32_t H, float* out, int64_t ld_out, int32_t accumulate,
+                            agnn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Persistent bidirectional GRU layer (one launch for all T steps), replacing `torch.nn.GRU` in the
  * hybrid branch (ref: models/cadence.py:249-285, models/analysis.py:527-537).  hidden must be 128

@@ -114,3 +114,46 @@ def test_empty_batch_kernels_do_not_launch():
     assert torch.equal(x.grad, torch.ones_like(x))
     out0 = ops.aggregate(ops.AggSpec(fwd=[fwd], bwd=[bwd], src_id=[0], n_rows=0, mean=True, shared_slot=True), [x])
     assert out0.shape == (0, 8)
+
+
+@pytest.mark.parametrize("shared,mean,H", [(True, True, 128), (False, True, 64), (True, False, 256), (False, False, 32)])
+def test_self_gradient_of_the_aggregation_matches_torch(shared, mean, H):
+    """d/d self of ops.aggregate (agnn_spmm_self_grad_f32) against autograd on the dense formula, with `self` a separate
+    matrix and with `self` being the source matrix itself (onset pooling: the two gradients are produced as one)."""
+    from analysisgnn_amd import ops
+    from analysisgnn_amd.graph import SegSpec, build_csr
+    rng = np.random.default_rng(H)
+    n, R = 97, 3
+    es = [rng.integers(0, n, size=(2, e)) for e in (400, 0, 150)]
+    specs = []
+    for e in es:
+        r, c = torch.from_numpy(e[0]).to(DEV), torch.from_numpy(e[1]).to(DEV)
+        specs += [SegSpec(r, c, n_rows=n), SegSpec(c, r, n_rows=n)]
+    csrs = build_csr(specs)
+    spec = ops.AggSpec(fwd=csrs[0::2], bwd=csrs[1::2], src_id=[0] * R, n_rows=n, mean=mean, shared_slot=shared)
+    x0 = torch.randn(n, H)
+    g = torch.randn(n, H if shared else R * H)
+
+    def dense(x, s):
+        outs = []
+        for e in es:
+            a = torch.zeros(n, n)
+            a.index_put_((torch.from_numpy(e[0]), torch.from_numpy(e[1])), torch.ones(e.shape[1]), accumulate=True)
+            cnt = a.sum(1, keepdim=True).clamp(min=1)
+            v = a @ x + s
+            outs.append(v / cnt if mean else v)
+        return sum(outs) if shared else torch.cat(outs, dim=1)
+
+    xr, sr = x0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+    dense(xr, sr).backward(g)
+    # separate matrices
+    xa, sa = x0.to(DEV).requires_grad_(True), x0.to(DEV).clone().requires_grad_(True)
+    out = ops.aggregate(spec, [xa], self_t=sa)
+    assert_close(out, dense(x0, x0), 1e-4, "forward")
+    out.backward(g.to(DEV))
+    assert_close(sa.grad, sr.grad, 1e-4, "d self")
+    assert_close(xa.grad, xr.grad, 1e-4, "d src")
+    # one matrix in both roles
+    xb = x0.to(DEV).requires_grad_(True)
+    ops.aggregate(spec, [xb], self_t=xb).backward(g.to(DEV))
+    assert_close(xb.grad, xr.grad + sr.grad, 1e-4, "d (src + self)")
