@@ -56,6 +56,12 @@ __global__ void k_count(SegTable t, uint32_t* __restrict__ keys, uint32_t* __res
   }
 }
 
+// counters and the heavy-row count start at zero.  A kernel, not hipMemsetAsync: a memset node inside a captured
+// single-stream graph was followed by an out-of-range write of k_scatter (stale counters) on ROCm 7.2.
+__global__ void k_zero_u32(uint32_t* __restrict__ p, int64_t n) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) p[i] = 0u;
+}
+
 // rowstart for an edge-less build
 __global__ void k_rowstart_zero(int32_t total_rows, int32_t* __restrict__ rowstart) {
   for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q <= total_rows; q += gridDim.x * blockDim.x) rowstart[q] = 0;
@@ -68,7 +74,8 @@ __global__ void k_scatter(const uint32_t* __restrict__ keys, int32_t e_total, ui
     const uint32_t key = keys[e];
     if (key >= sentinel) continue;
     const uint32_t slot = atomicSub(cnt + key, 1u) - 1u;
-    vals[static_cast<uint32_t>(rowstart[key]) + slot] = static_cast<uint32_t>(e);
+    const uint32_t pos = static_cast<uint32_t>(rowstart[key]) + slot;
+    if (pos < static_cast<uint32_t>(e_total)) vals[pos] = static_cast<uint32_t>(e);   // always true with clean counters; never write outside
   }
 }
 
@@ -239,8 +246,11 @@ extern "C" int agnn_csr_build(int n_seg, const agnn_coo_seg_t* segs, int32_t* ro
   void* temp = ws + l.temp;
   size_t temp_bytes = l.temp_bytes;
 
-  hipError_t e = hipMemsetAsync(cnt, 0, static_cast<size_t>(r_total + 2) * sizeof(uint32_t), stream);
-  if (e != hipSuccess) return fail(AGNN_ERUNTIME, "csr_build/memset: %s", hipGetErrorString(e));
+  int blocks_z = static_cast<int>((r_total + 2 + threads - 1) / threads);
+  if (blocks_z > 2048) blocks_z = 2048;
+  hipLaunchKernelGGL(k_zero_u32, dim3(blocks_z), dim3(threads), 0, stream, cnt, r_total + 2);
+  if (int rc = check_launch("csr_build/zero")) return rc;
+  hipError_t e = hipSuccess;
   int blocks = static_cast<int>((e_total + threads - 1) / threads);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(k_count, dim3(blocks), dim3(threads), 0, stream, t, keys, cnt);
