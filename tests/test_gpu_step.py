@@ -113,3 +113,57 @@ def test_adjacent_parameter_layout_gives_the_same_step():
             assert p.grad is not None and torch.equal(p.grad, ga[n].grad), n
     finally:
         graph.index_cache_enabled = was
+
+
+def test_single_stream_captured_step_is_stable_over_many_replays():
+    """The step captured on ONE stream (sequence branch and weight gradients on the main stream) takes ROCm's fast replay
+    path, where a memset node once left stale counters to the CSR build (an out-of-range write after a few replays): 40
+    replays must keep producing the eager gradients."""
+    from analysisgnn_amd import dp, graph
+    from analysisgnn_amd.encoders import _HybridMixin
+    from analysisgnn_amd.heads import training_loss
+    from analysisgnn_amd.models import TorchAnalysisGNN
+    from analysisgnn_amd.synth import make_batch, torch_inputs
+    dev = torch.device("cuda", 0)
+    tasks = {"cadence": 4, "localkey": 50, "romanNumeral": 185}
+    g = make_batch(4, 500)
+    I = torch_inputs(g, 25, dev, seed=0)
+    labels = torch.stack([torch.randint(0, c, (I["batch_size"],), generator=torch.Generator().manual_seed(i)).to(dev)
+                          for i, c in enumerate(tasks.values())])
+    torch.manual_seed(0)
+    model = TorchAnalysisGNN(g.metadata(), 25, 256, 128, tasks, 3, dropout=0.0, use_jk=False).to(dev).train()
+    params, tight = dp.plan_parameters(model)
+    flat = dp.FlatGradBuffer(params, views=False, tight=tight)
+    was, was_overlap = graph.index_cache_enabled, _HybridMixin.overlap_sequence_branch
+    graph.index_cache_enabled = False
+    _HybridMixin.overlap_sequence_branch = False
+    dp.enable_wgrad_overlap(False)
+    try:
+        def fwd_bwd():
+            flat.zero()
+            x = model.encode(I["pitch_spelling"], I["key_signature"], I["x_dict"], I["edge_index_dict"], I["batch_dict"],
+                             I["batch_size"], None, None)
+            logits, offs, _ = model.forward_clf_fused(x)
+            loss, _ = training_loss(logits, offs, labels, x, 0.1, 0.1, -1)
+            loss.backward()
+            flat.pack()
+            return loss
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                fwd_bwd()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        g_eager = flat.flat.clone()
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
+            fwd_bwd()
+        for _ in range(40):
+            cg.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(flat.flat, g_eager), float((flat.flat - g_eager).abs().max())
+    finally:
+        graph.index_cache_enabled = was
+        _HybridMixin.overlap_sequence_branch = was_overlap
