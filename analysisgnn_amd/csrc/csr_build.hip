@@ -10,8 +10,9 @@
 //   scan       exclusive sum of the counters = rowstart (library scan)
 //   k_scatter  edge id -> rowstart[key] + slot, slot handed out by atomicSub on the same counters (which are zero
 //              again afterwards); the order INSIDE a row is whatever the atomics gave ...
-//   k_rows     ... and is made the stable one here: one thread per row sorts its <= 32 edge ids in place and emits
-//              col / perm; longer rows go to a list
+//   k_rows     ... and is made the stable one here: one thread per row sorts its <= 8 edge ids in registers; longer
+//              rows go to a list
+//   k_emit     col / perm of those rows, one thread per edge position (coalesced)
 //   k_heavy    one wavefront per listed row: rank of every id among the row's ids (O(d^2 / 64)), col / perm written at
 //              the rank; also zero-fills the slots behind the kept edges
 // Integer atomics only decide intermediate positions; the result is the unique stable order (bit-identical to the
@@ -69,48 +70,73 @@ __global__ void k_rowstart_zero(int32_t total_rows, int32_t* __restrict__ rowsta
 
 // vals[rowstart[key] + slot] = edge id; the counters return to zero
 __global__ void k_scatter(const uint32_t* __restrict__ keys, int32_t e_total, uint32_t sentinel,
-                          const int32_t* __restrict__ rowstart, uint32_t* __restrict__ cnt, uint32_t* __restrict__ vals) {
+                          const int32_t* __restrict__ rowstart, uint32_t* __restrict__ cnt, uint32_t* __restrict__ vals,
+                          uint32_t* __restrict__ rowof) {
   for (int32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < e_total; e += gridDim.x * blockDim.x) {
     const uint32_t key = keys[e];
     if (key >= sentinel) continue;
     const uint32_t slot = atomicSub(cnt + key, 1u) - 1u;
     const uint32_t pos = static_cast<uint32_t>(rowstart[key]) + slot;
-    if (pos < static_cast<uint32_t>(e_total)) vals[pos] = static_cast<uint32_t>(e);   // always true with clean counters; never write outside
+    if (pos < static_cast<uint32_t>(e_total)) {                 // always true with clean counters; never write outside
+      vals[pos] = static_cast<uint32_t>(e);
+      rowof[pos] = key;
+    }
   }
 }
 
-constexpr int kSmallRow = 32;
+constexpr int kSmallRow = 8;
 
-// one thread per row: rows of <= kSmallRow edges are sorted in place (insertion sort on ascending edge id = the
-// original order) and emitted; longer rows are appended to `heavy`
+// one thread per row: rows of 2 .. kSmallRow (= 8) edges are sorted in registers — eight predicated loads in flight, a
+// 19-exchange sorting network, predicated stores; an insertion sort on global memory is a chain of dependent round trips
+// (110 us for the 18-edge measure rows of the C3 graph).  Longer rows are appended to `heavy` (one wavefront each).
+// col / perm of the short rows are written by k_emit.
+__device__ __forceinline__ void cex(uint32_t& a, uint32_t& b) {
+  const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+  a = lo;
+  b = hi;
+}
+
 __global__ void k_rows(SegTable t, const int32_t* __restrict__ rowstart, uint32_t* __restrict__ vals,
-                       int32_t* __restrict__ col, int32_t* __restrict__ perm, uint32_t* __restrict__ heavy_n,
-                       uint32_t* __restrict__ heavy) {
+                       uint32_t* __restrict__ heavy_n, uint32_t* __restrict__ heavy) {
+  static_assert(kSmallRow == 8, "the sorting network below is for 8 keys");
   const int32_t r_total = t.rbase[t.n_seg];
   for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < r_total; q += gridDim.x * blockDim.x) {
     const int32_t s0 = rowstart[q], d = rowstart[q + 1] - s0;
-    if (d <= 0) continue;
+    if (d <= 1) continue;
     if (d > kSmallRow) {
       heavy[atomicAdd(heavy_n, 1u)] = static_cast<uint32_t>(q);
       continue;
     }
     uint32_t* v = vals + s0;
-    for (int i = 1; i < d; ++i) {
-      const uint32_t x = v[i];
-      int j = i - 1;
-      while (j >= 0 && v[j] > x) { v[j + 1] = v[j]; --j; }
-      v[j + 1] = x;
-    }
+    uint32_t a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = i < d ? v[i] : 0xffffffffu;      // padding sorts to the end
+    // Batcher's odd-even merge sort for 8 keys
+    cex(a[0], a[1]); cex(a[2], a[3]); cex(a[4], a[5]); cex(a[6], a[7]);
+    cex(a[0], a[2]); cex(a[1], a[3]); cex(a[4], a[6]); cex(a[5], a[7]);
+    cex(a[1], a[2]); cex(a[5], a[6]);
+    cex(a[0], a[4]); cex(a[1], a[5]); cex(a[2], a[6]); cex(a[3], a[7]);
+    cex(a[2], a[4]); cex(a[3], a[5]);
+    cex(a[1], a[2]); cex(a[3], a[4]); cex(a[5], a[6]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < d) v[i] = a[i];
+  }
+}
+
+// one thread per kept edge position (coalesced): col / perm of every row of <= kSmallRow edges
+__global__ void k_emit(SegTable t, const int32_t* __restrict__ rowstart, const uint32_t* __restrict__ vals,
+                       const uint32_t* __restrict__ rowof, int32_t* __restrict__ col, int32_t* __restrict__ perm) {
+  const int32_t kept = rowstart[t.rbase[t.n_seg]];
+  for (int32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < kept; p += gridDim.x * blockDim.x) {
+    const int32_t q = static_cast<int32_t>(rowof[p]);
+    if (rowstart[q + 1] - rowstart[q] > kSmallRow) continue;        // emitted by k_heavy
     int sg = 0;
 #pragma unroll 1
     while (sg + 1 < t.n_seg && q >= t.rbase[sg + 1]) ++sg;
-    const int64_t* cs = t.col[sg];
-    const int32_t eb = t.ebase[sg];
-    for (int i = 0; i < d; ++i) {
-      const int32_t le = static_cast<int32_t>(v[i]) - eb;
-      col[s0 + i] = static_cast<int32_t>(cs[le]);
-      perm[s0 + i] = le;
-    }
+    const int32_t le = static_cast<int32_t>(vals[p]) - t.ebase[sg];
+    col[p] = static_cast<int32_t>(t.col[sg][le]);
+    perm[p] = le;
   }
 }
 
@@ -176,7 +202,7 @@ size_t scan_temp_bytes(int64_t total_rows) {
 }
 
 struct Layout {
-  size_t keys, vals, cnt, heavy, temp, temp_bytes, total;
+  size_t keys, vals, rowof, cnt, heavy, temp, temp_bytes, total;
 };
 
 Layout make_layout(int64_t e_total, int64_t total_rows) {
@@ -185,6 +211,7 @@ Layout make_layout(int64_t e_total, int64_t total_rows) {
   size_t off = 0;
   l.keys = off; off += align_up(e * sizeof(uint32_t));
   l.vals = off; off += align_up(e * sizeof(uint32_t));
+  l.rowof = off; off += align_up(e * sizeof(uint32_t));
   l.cnt = off; off += align_up((r + 2) * sizeof(uint32_t));              // counters [total_rows + 1], then the heavy-row count
   l.heavy = off; off += align_up((e / (kSmallRow + 1) + 1) * sizeof(uint32_t));
   l.temp = off;
@@ -240,6 +267,7 @@ extern "C" int agnn_csr_build(int n_seg, const agnn_coo_seg_t* segs, int32_t* ro
   char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t{255});
   uint32_t* keys = reinterpret_cast<uint32_t*>(ws + l.keys);
   uint32_t* vals = reinterpret_cast<uint32_t*>(ws + l.vals);
+  uint32_t* rowof = reinterpret_cast<uint32_t*>(ws + l.rowof);
   uint32_t* cnt = reinterpret_cast<uint32_t*>(ws + l.cnt);
   uint32_t* heavy_n = cnt + r_total + 1;
   uint32_t* heavy = reinterpret_cast<uint32_t*>(ws + l.heavy);
@@ -258,14 +286,16 @@ extern "C" int agnn_csr_build(int n_seg, const agnn_coo_seg_t* segs, int32_t* ro
   e = hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, cnt, rowstart, static_cast<int>(r_total + 1), stream);
   if (e != hipSuccess) return fail(AGNN_ERUNTIME, "csr_build/scan: %s", hipGetErrorString(e));
   hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(threads), 0, stream, keys, static_cast<int32_t>(e_total),
-                     static_cast<uint32_t>(r_total), rowstart, cnt, vals);
+                     static_cast<uint32_t>(r_total), rowstart, cnt, vals, rowof);
   if (int rc = check_launch("csr_build/scatter")) return rc;
   int blocks_r = static_cast<int>((r_total + threads - 1) / threads);
   if (blocks_r > 4096) blocks_r = 4096;
   if (blocks_r < 1) blocks_r = 1;
-  hipLaunchKernelGGL(k_rows, dim3(blocks_r), dim3(threads), 0, stream, t, rowstart, vals, col, perm, heavy_n, heavy);
+  hipLaunchKernelGGL(k_rows, dim3(blocks_r), dim3(threads), 0, stream, t, rowstart, vals, heavy_n, heavy);
   if (int rc = check_launch("csr_build/rows")) return rc;
-  hipLaunchKernelGGL(k_heavy, dim3(256), dim3(256), 0, stream, t, rowstart, vals, col, perm, heavy_n, heavy);
+  hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(threads), 0, stream, t, rowstart, vals, rowof, col, perm);
+  if (int rc = check_launch("csr_build/emit")) return rc;
+  hipLaunchKernelGGL(k_heavy, dim3(1024), dim3(256), 0, stream, t, rowstart, vals, col, perm, heavy_n, heavy);
   return check_launch("csr_build/heavy");
 }
 
