@@ -97,10 +97,11 @@ class _HGTAttention(torch.autograd.Function):
             offs.append(offs[-1] + k_)
         a_all = torch.empty((offs[-1], heads), dtype=torch.float32, device=dev)
         g_all = torch.empty((offs[-1], heads), dtype=torch.float32, device=dev)
-        t_all = torch.zeros((offs[-1], heads), dtype=torch.float32, device=dev)
         alpha = [a_all[offs[r]:offs[r + 1]] for r in range(R)]
         gs = [g_all[offs[r]:offs[r + 1]] for r in range(R)]
-        tdot = [t_all[offs[r]:offs[r + 1]] for r in range(R)]
+        # tdot as [R, max E_r, heads] (zero padded): the per-relation sums over edges are ONE reduction instead of R
+        t3 = torch.zeros((max(R, 1), max(ne) if ne else 1, heads), dtype=torch.float32, device=dev)
+        tdot = [t3[r, :ne[r]] for r in range(R)]
         rels = (_lib.HgtRel * max(R, 1))()
         keep = []
         for r in range(R):
@@ -118,7 +119,7 @@ class _HGTAttention(torch.autograd.Function):
                                                      out.data_ptr(), out.stride(0), m.data_ptr(), linv.data_ptr(), n, H,
                                                      heads, dq.data_ptr(), dq.stride(0), _lib.stream_ptr(dev)),
                        "agnn_hgt_attn_bwd_dst_f32")
-        dps = torch.stack([t.sum(dim=0) for t in tdot]) if R else torch.zeros_like(pscale)
+        dps = t3.sum(dim=1) if R else torch.zeros_like(pscale)
         grads = []
         for r in range(R):
             c = spec.bwd[r]
@@ -146,6 +147,7 @@ class _ColSplit(torch.autograd.Function):
     def forward(ctx, big, G: int):
         N, W = big.shape
         ctx.meta = (N, W, G)
+        ctx.set_materialize_grads(False)           # unused blocks: zero-filled in place below, not as separate tensors first
         H = W // G
         return tuple(big[:, g * H:(g + 1) * H] for g in range(G))
 
@@ -153,7 +155,9 @@ class _ColSplit(torch.autograd.Function):
     def backward(ctx, *grads):
         N, W, G = ctx.meta
         H = W // G
-        ref = next(g for g in grads if g is not None)
+        ref = next((g for g in grads if g is not None), None)
+        if ref is None:
+            return None, None
         dbig = torch.empty((N, W), dtype=torch.float32, device=ref.device)
         items = []
         for g_i, g in enumerate(grads):
@@ -284,7 +288,7 @@ class HGTConv(nn.Module):
             o = self.out_lin.lins[t](F.gelu(m))
             if o.shape[-1] == x.shape[-1]:
                 beta = torch.sigmoid(self.skip[t])
-                o = beta * o + (1 - beta) * (x if n >= x.shape[0] else x[:n])
+                o = torch.lerp(x if n >= x.shape[0] else x[:n], o, beta)          # beta * o + (1 - beta) * x in one launch
             out[t] = o
         return out
 
