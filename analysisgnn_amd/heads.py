@@ -164,7 +164,7 @@ def multitask_cross_entropy(logits: torch.Tensor, offs: Sequence[int], labels: t
 
 
 _OFFS_CACHE: Dict[tuple, torch.Tensor] = {}
-_LOSS_WS: Dict[tuple, torch.Tensor] = {}
+_LOSS_WS: Dict[str, torch.Tensor] = {}
 
 
 class _TrainLoss(torch.autograd.Function):
@@ -182,10 +182,9 @@ class _TrainLoss(torch.autograd.Function):
         T = offs_t.numel() - 1
         labels = labels.contiguous()
         lib = _lib.load()
-        key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)     # one ticket per stream: calls on different streams may overlap
-        ws = _LOSS_WS.get(key)
+        ws = _LOSS_WS.get(str(dev))
         if ws is None:                                        # zero-filled once; every call leaves it zero-filled
-            ws = _LOSS_WS[key] = torch.zeros(int(lib.agnn_train_loss_workspace_bytes()) + 256, dtype=torch.uint8, device=dev)
+            ws = _LOSS_WS[str(dev)] = torch.zeros(int(lib.agnn_train_loss_workspace_bytes()) + 256, dtype=torch.uint8, device=dev)
         wsp = (ws.data_ptr() + 255) & ~255
         row_loss = torch.empty((T, N), dtype=torch.float32, device=dev)
         out = torch.empty((2 * T + 1,), dtype=torch.float32, device=dev)      # loss[T] | inv_cnt[T] | total
