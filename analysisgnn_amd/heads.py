@@ -182,7 +182,7 @@ class _TrainLoss(torch.autograd.Function):
         T = offs_t.numel() - 1
         labels = labels.contiguous()
         lib = _lib.load()
-        ws = _LOSS_WS.get(str(dev))
+        ws = _LOSS_WS.get(str(dev))                           # one per device: calls on one device are assumed not to overlap
         if ws is None:                                        # zero-filled once; every call leaves it zero-filled
             ws = _LOSS_WS[str(dev)] = torch.zeros(int(lib.agnn_train_loss_workspace_bytes()) + 256, dtype=torch.uint8, device=dev)
         wsp = (ws.data_ptr() + 255) & ~255
