@@ -205,6 +205,42 @@ def _index_tensor(ids: tuple, device) -> torch.Tensor:
     return _SEL_CACHE[key]
 
 
+class _BlockDiagWeight(torch.autograd.Function):
+    """The operand of x W^T for the relations `rel_ids` leaving one source type: row block r holds (blockdiag_h A_{r,h})^T,
+    i.e. out[r*H + h*D + j, h*D + i] = weight[rel_ids[r]*heads + h, i, j] and zeros elsewhere, so that
+    (x W^T)[:, r*H:(r+1)*H] = concat_h(x_h A_{r,h}).  Three launches forward (zeros, gather, block scatter), three
+    backward (gather of the diagonal blocks, zeros, scatter) — plain indexing costs ~15 and its autograd chain as many."""
+
+    @staticmethod
+    def forward(ctx, weight, rel_ids: tuple, n_rel: int, heads: int, D: int):
+        dev = weight.device
+        R, H = len(rel_ids), heads * D
+        sel = _index_tensor(tuple(r * heads + h for r in rel_ids for h in range(heads)), dev)      # [R*heads]
+        blocks = weight.detach().index_select(0, sel).view(R, heads, D, D)                         # A_{r,h}[i, j]
+        out = weight.new_zeros((R, heads, D, heads, D))                                             # [r, h, j, h', i]
+        ar = _arange(heads, dev)
+        out[:, ar, :, ar, :] = blocks.permute(1, 0, 3, 2)                                           # (h, r, j, i) -> out[r, h, j, h, i]
+        ctx.sel, ctx.meta = sel, (R, heads, D, weight.shape[0])
+        return out.view(R * H, H)
+
+    @staticmethod
+    def backward(ctx, g):
+        R, heads, D, T = ctx.meta
+        ar = _arange(heads, g.device)
+        gb = g.reshape(R, heads, D, heads, D)[:, ar, :, ar, :]                                      # [h, r, j, i]
+        gw = g.new_zeros((T, D, D))
+        gw.index_copy_(0, ctx.sel, gb.permute(1, 0, 3, 2).reshape(R * heads, D, D))                # back to [r*heads + h, i, j]
+        return gw, None, None, None, None
+
+
+def _arange(n: int, device) -> torch.Tensor:
+    return _index_tensor(tuple(range(n)), device)
+
+
+def block_diag_weight(weight: torch.Tensor, rel_ids: tuple, n_rel: int, heads: int, D: int) -> torch.Tensor:
+    return _BlockDiagWeight.apply(weight, rel_ids, n_rel, heads, D)
+
+
 class HGTConv(nn.Module):
     def __init__(self, in_channels: int, out_channels: int, metadata, heads: int = 1):
         super().__init__()
@@ -246,29 +282,18 @@ class HGTConv(nn.Module):
         used = sorted({e_idx for rels in by_dst.values() for e_idx, _ in rels})
         kv_of: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
         if used:
-            dev = next(iter(x_dict.values())).device
-            ar = torch.arange(heads, device=dev)
-            sel = _index_tensor(tuple(used), dev)
-
-            def dense(weight):
-                w4 = weight.view(len(self.edge_types), heads, D, D).index_select(0, sel)      # [R, heads, D, D]
-                wb = w4.new_zeros(len(used), heads, D, heads, D)
-                wb[:, ar, :, ar, :] = w4.permute(1, 0, 2, 3)                                # block (h, h) of relation r
-                return wb.view(len(used), H, H)
-            Wk, Wv = dense(self.k_rel.weight), dense(self.v_rel.weight)
             # all relations leaving one source type share their input: ONE GEMM [N_s, H] x [H, R_s*H] for the keys and one
             # for the values (weight gradient [R_s*H, H] in one piece), the relations' blocks handed out as column views
             by_src: Dict[str, List[int]] = {}
-            for i, e_idx in enumerate(used):
-                by_src.setdefault(self.edge_types[e_idx][0], []).append(i)
-            for s_t, pos in by_src.items():
-                sel_s = _index_tensor(tuple(pos), dev)
-                Wk_s = Wk.index_select(0, sel_s).transpose(1, 2).reshape(len(pos) * H, H)      # rows r*H..: (k A_r)^T layout for x W^T
-                Wv_s = Wv.index_select(0, sel_s).transpose(1, 2).reshape(len(pos) * H, H)
-                ks = col_split(linear(k[s_t], Wk_s), len(pos))
-                vs = col_split(linear(v[s_t], Wv_s), len(pos))
-                for j, i in enumerate(pos):
-                    kv_of[used[i]] = (ks[j], vs[j])
+            for e_idx in used:
+                by_src.setdefault(self.edge_types[e_idx][0], []).append(e_idx)
+            for s_t, e_ids in by_src.items():
+                Wk_s = block_diag_weight(self.k_rel.weight, tuple(e_ids), len(self.edge_types), heads, D)     # [R_s*H, H]
+                Wv_s = block_diag_weight(self.v_rel.weight, tuple(e_ids), len(self.edge_types), heads, D)
+                ks = col_split(linear(k[s_t], Wk_s), len(e_ids))
+                vs = col_split(linear(v[s_t], Wv_s), len(e_ids))
+                for j, e_idx in enumerate(e_ids):
+                    kv_of[e_idx] = (ks[j], vs[j])
         out = {}
         for t, x in x_dict.items():
             n = n_of[t]
