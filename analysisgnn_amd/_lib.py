@@ -25,6 +25,14 @@ class CooSeg(C.Structure):
                 ("etype_code", C.c_int64), ("n_edges", C.c_int64), ("n_rows", C.c_int64)]
 
 
+class RowendItem(C.Structure):
+    _fields_ = [("rowptr", C.c_void_p), ("perm", C.c_void_p), ("rowend", C.c_void_p), ("n_rows", C.c_int32),
+                ("e_limit", C.c_int32)]
+
+
+ROWEND_MAX_ITEMS = 64
+
+
 class Rel(C.Structure):
     _fields_ = [("src", C.c_void_p), ("rowptr", C.c_void_p), ("rowend", C.c_void_p), ("col", C.c_void_p),
                 ("ew", C.c_void_p), ("colscale", C.c_void_p), ("ld_src", C.c_int64)]
@@ -60,6 +68,7 @@ SIGNATURES = {
     "agnn_csr_build": (C.c_int, [C.c_int, C.POINTER(CooSeg), C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
     "agnn_csr_rowend": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "agnn_csr_rowend_batch": (C.c_int, [C.c_int, C.POINTER(RowendItem), C.c_void_p]),
     "agnn_spmm_f32": (C.c_int, [C.c_int, C.POINTER(Rel), C.c_int64, C.c_int32, C.c_void_p, C.c_int64,
                                 C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_uint32,
                                 C.c_void_p]),
@@ -103,8 +112,9 @@ SIGNATURES = {
                                          C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "agnn_train_loss_workspace_bytes": (C.c_size_t, []),
     "agnn_train_loss_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_float, C.c_int64,
-                                      C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+                                      C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                      C.c_void_p]),
     "agnn_train_loss_bwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_int64,
                                           C.c_void_p]),

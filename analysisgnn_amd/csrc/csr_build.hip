@@ -192,6 +192,24 @@ __global__ void k_rowend(const int32_t* __restrict__ rowptr, const int32_t* __re
   }
 }
 
+struct RowendBatch {
+  agnn_rowend_item_t it[AGNN_ROWEND_MAX_ITEMS];
+};
+
+// blockIdx.y = item; the items of a batch (relations x directions x trimmed layers of one sampled batch) differ in size
+// by small factors only, so surplus blocks of the shorter ones just leave
+__global__ __launch_bounds__(256) void k_rowend_batch(RowendBatch b) {
+  const agnn_rowend_item_t& I = b.it[blockIdx.y];
+  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < I.n_rows; i += gridDim.x * blockDim.x) {
+    int32_t lo = I.rowptr[i], hi = I.rowptr[i + 1];
+    while (lo < hi) {  // perm is increasing inside a row (stable sort)
+      const int32_t mid = lo + ((hi - lo) >> 1);
+      if (I.perm[mid] < I.e_limit) lo = mid + 1; else hi = mid;
+    }
+    I.rowend[i] = lo;
+  }
+}
+
 inline size_t align_up(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 
 size_t scan_temp_bytes(int64_t total_rows) {
@@ -313,4 +331,25 @@ extern "C" int agnn_csr_rowend(const int32_t* rowptr, const int32_t* perm, int64
   hipLaunchKernelGGL(k_rowend, dim3(blocks), dim3(threads), 0, static_cast<hipStream_t>(stream_), rowptr,
                      perm, static_cast<int32_t>(n_rows), static_cast<int32_t>(e_limit), rowend);
   return check_launch("csr_rowend");
+}
+
+extern "C" int agnn_csr_rowend_batch(int n_items, const agnn_rowend_item_t* items, agnn_stream_t stream_) {
+  using namespace agnn;
+  if (n_items < 0 || n_items > AGNN_ROWEND_MAX_ITEMS) return fail(AGNN_EINVAL, "csr_rowend_batch: n_items=%d not in [0,%d]", n_items, AGNN_ROWEND_MAX_ITEMS);
+  if (n_items == 0) return AGNN_OK;
+  if (!items) return fail(AGNN_EINVAL, "csr_rowend_batch: null argument");
+  RowendBatch b{};
+  int32_t max_rows = 0;
+  for (int i = 0; i < n_items; ++i) {
+    b.it[i] = items[i];
+    if (items[i].n_rows < 0) return fail(AGNN_EINVAL, "csr_rowend_batch: item %d has n_rows=%d", i, items[i].n_rows);
+    if (items[i].n_rows > 0 && (!items[i].rowptr || !items[i].perm || !items[i].rowend)) return fail(AGNN_EINVAL, "csr_rowend_batch: item %d has a null pointer", i);
+    if (b.it[i].e_limit < 0) b.it[i].e_limit = 0;
+    if (items[i].n_rows > max_rows) max_rows = items[i].n_rows;
+  }
+  if (max_rows == 0) return AGNN_OK;
+  int bx = (max_rows + 255) / 256;
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(k_rowend_batch, dim3(bx, n_items), dim3(256), 0, static_cast<hipStream_t>(stream_), b);
+  return check_launch("csr_rowend_batch");
 }

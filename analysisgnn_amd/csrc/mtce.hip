@@ -70,9 +70,13 @@ __global__ __launch_bounds__(256) void k_mtce(const float* __restrict__ z, int64
     const int a = off[t], b = off[t + 1];
     const int C = b - a;
     if (C <= 0) continue;
-    const int64_t y = labels[static_cast<int64_t>(t) * n_rows + row];
-    const bool valid = (y != ignore);
-    const float sc = valid ? 1.f : 0.f;              // per-task 1/count and the incoming gradient are applied by k_mtce_scale
+    const int64_t y_raw = labels[static_cast<int64_t>(t) * n_rows + row];
+    const bool valid = (y_raw != ignore);
+    // A label outside [0, C) that is not the ignore value: torch's CrossEntropyLoss raises a device assert.  Here the row's
+    // loss and gradient become NaN (loud in the total and in every gradient downstream) and nothing is read out of range.
+    const bool bad = valid && (y_raw < 0 || y_raw >= C);
+    const int64_t y = bad ? 0 : y_raw;
+    const float sc = valid ? (bad ? NAN : 1.f) : 0.f;   // per-task 1/count and the incoming gradient are applied by k_mtce_scale
     float loss;
     const int nk = (C + 15) >> 4;
     if (nk == 1) task_regs<1>(zr, dr, a, b, sub, y, valid, sc, eps, loss);
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void k_mtce(const float* __restrict__ z, int64
         dr[c] = sc * (p - (((c - a) == y ? 1.f - eps : 0.f) + sm));
       }
     }
-    if (sub == 0) row_loss[static_cast<int64_t>(t) * n_rows + row] = loss;     // task-major: the reduction reads contiguously
+    if (sub == 0) row_loss[static_cast<int64_t>(t) * n_rows + row] = bad ? NAN : loss;     // task-major: the reduction reads contiguously
   }
 }
 
@@ -150,8 +154,11 @@ __global__ __launch_bounds__(256) void k_mtce_scale(const float* __restrict__ dz
   }
 }
 
-// Training loss in two launches:  total = sum_t loss[t] + lambda * mean(feat^2)
-// (ref: models/analysis.py:984 `feature_loss = x.pow(2).mean()`, :1072 `total_loss += ... feature_loss * self.lambda_featl`).
+// Training loss in two launches:  total = ce_scale * sum_t (w_t * loss[t] + reg_t) + lambda * mean(feat^2)
+// (ref: models/analysis.py:1034-1036 `total_loss = loss_dict.pop("total") / len(labels_dict)`, :984 `feature_loss =
+// x.pow(2).mean()`, :1072 `total_loss += ... feature_loss * self.lambda_featl`).  With learned uncertainty weights p
+// (MultiTaskLoss, models/chord.py:39-49, the CLI default --mt_strategy wloss): w_t = 0.5 / p_t^2, reg_t = log(1 + p_t^2);
+// without: w_t = 1, reg_t = 0.
 // Blocks 0 .. T-1 reduce one task each (as k_mtce_reduce), blocks T .. T+kFeatBlocks-1 reduce a fixed slice of feat^2;
 // the last block to finish (integer ticket) adds the T + kFeatBlocks partial results in index order and resets the ticket:
 // the result does not depend on which block that was.
@@ -161,7 +168,9 @@ __global__ __launch_bounds__(1024) void k_train_loss_reduce(const float* __restr
                                                             int64_t n_rows, int64_t ignore, int T, float* __restrict__ loss,
                                                             float* __restrict__ inv_cnt, const float* __restrict__ feat, int64_t ld_feat,
                                                             int feat_cols, float lam_over_numel, float* __restrict__ fpart,
-                                                            unsigned int* __restrict__ ticket, float* __restrict__ total) {
+                                                            unsigned int* __restrict__ ticket, float* __restrict__ total,
+                                                            const float* __restrict__ task_param, float ce_scale,
+                                                            float* __restrict__ wscale, float* __restrict__ dparam) {
   __shared__ float sl[1024];
   __shared__ int sc[1024];
   __shared__ bool last;
@@ -238,18 +247,39 @@ __global__ __launch_bounds__(1024) void k_train_loss_reduce(const float* __restr
     }
     const unsigned int before = atomicExch(pub + t, __float_as_uint(val));
     asm volatile("" ::"v"(before));                    // the exchange has completed before the ticket is taken
+    if (t < T) {                                       // the count travels the same way (the weighted gradient scale needs it)
+      const unsigned int b2 = atomicExch(pub + 1024 + t, __float_as_uint(inv_cnt[t]));
+      asm volatile("" ::"v"(b2));
+    }
     last = atomicAdd(ticket, 1u) == gridDim.x - 1;
   }
   __syncthreads();
   if (last) {                                          // block-uniform
     const int tid = threadIdx.x;                       // T + kFeatBlocks <= 1024 (host-checked): one value per thread, then a serial sum in LDS
     if (tid < T + kFeatBlocks) sl[tid] = __uint_as_float(atomicOr(pub + tid, 0u));
+    if (tid < T) {                                     // per-task weight, gradient scale and d total / d p_t
+      float w = 1.f, dp = 0.f;
+      if (task_param != nullptr) {
+        const float p = task_param[tid], p2 = p * p;
+        w = 0.5f / p2;
+        dp = ce_scale * (2.f * p / (1.f + p2) - sl[tid] / (p2 * p));
+      }
+      if (wscale != nullptr) wscale[tid] = ce_scale * w * __uint_as_float(atomicOr(pub + 1024 + tid, 0u));
+      if (dparam != nullptr) dparam[tid] = dp;
+    }
     __syncthreads();
     if (tid == 0) {
       float tot = 0.f, f = 0.f;
-      for (int i = 0; i < T; ++i) tot += sl[i];
+      for (int i = 0; i < T; ++i) {
+        if (task_param != nullptr) {
+          const float p2 = task_param[i] * task_param[i];
+          tot += 0.5f / p2 * sl[i] + logf(1.f + p2);
+        } else {
+          tot += sl[i];
+        }
+      }
       for (int i = 0; i < kFeatBlocks; ++i) f += sl[T + i];
-      *total = fmaf(f, lam_over_numel, tot);
+      *total = fmaf(f, lam_over_numel, ce_scale * tot);
       atomicExch(ticket, 0u);
     }
   }
@@ -346,12 +376,13 @@ extern "C" int agnn_multitask_ce_scale_f32(const float* dlogits, int64_t ld, con
   return check_launch("multitask_ce_scale");
 }
 
-extern "C" size_t agnn_train_loss_workspace_bytes(void) { return 256 + 1024 * sizeof(float); }
+extern "C" size_t agnn_train_loss_workspace_bytes(void) { return 256 + 2048 * sizeof(float); }
 
 extern "C" int agnn_train_loss_f32(const float* logits, int64_t ld, const int32_t* seg_off, int32_t n_tasks, const int64_t* labels,
                                    int64_t n_rows, float label_smoothing, int64_t ignore_index, const float* feat, int64_t ld_feat,
-                                   int32_t feat_cols, float lambda_feat, float* row_loss, float* dlogits, float* loss,
-                                   float* inv_count, float* total, void* workspace, size_t workspace_bytes, agnn_stream_t stream_) {
+                                   int32_t feat_cols, float lambda_feat, const float* task_param, float ce_scale, float* row_loss,
+                                   float* dlogits, float* loss, float* inv_count, float* total, float* wscale, float* dparam,
+                                   void* workspace, size_t workspace_bytes, agnn_stream_t stream_) {
   using namespace agnn;
   if (n_rows <= 0 || n_tasks <= 0 || n_tasks > 1024 - kFeatBlocks || ld < 0) return fail(AGNN_EINVAL, "train_loss: n_rows=%lld n_tasks=%d", (long long)n_rows, n_tasks);
   if (!logits || !seg_off || !labels || !row_loss || !dlogits || !loss || !inv_count || !total || !workspace) return fail(AGNN_EINVAL, "train_loss: null argument");
@@ -367,7 +398,7 @@ extern "C" int agnn_train_loss_f32(const float* logits, int64_t ld, const int32_
   float* fpart = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + 256);
   const float lam = feat ? lambda_feat / (static_cast<float>(n_rows) * static_cast<float>(feat_cols)) : 0.f;
   hipLaunchKernelGGL(k_train_loss_reduce, dim3(n_tasks + kFeatBlocks), dim3(1024), 0, s, row_loss, labels, n_rows, ignore_index, n_tasks,
-                     loss, inv_count, feat, ld_feat, feat_cols, lam, fpart, ticket, total);
+                     loss, inv_count, feat, ld_feat, feat_cols, lam, fpart, ticket, total, task_param, ce_scale, wscale, dparam);
   return check_launch("train_loss/reduce");
 }
 

@@ -320,19 +320,27 @@ __global__ __launch_bounds__(256) void k_spmm_fast(RelTable t, SpmmArgs a) {
 // k_spmm_fast: per relation {pointer from the kernel-argument table -> rowptr[row] -> rowptr[row+1]} one after the
 // other, then the column ids, then per relation {gather -> store}, with every later gather also waiting for the
 // previous relation's store (vmcnt counts loads and stores in issue order).  Here:
-//   * the table is a structure of arrays, so the four rowptr / col / src pointers come with one scalar load each,
-//     and entries beyond n_rel repeat the last relation: no branch anywhere in the index phase;
-//   * all four rowptr pairs are one batch of scalar loads, all four column-id vectors one batch of vector loads,
-//     the first two neighbour rows of all four relations (8 loads; rows have ~1.6 neighbours per relation) one
+//   * the table is a structure of arrays, so the four rowptr / rowend / col / src pointers come with one scalar load
+//     each, and entries beyond n_rel repeat the last relation: no branch anywhere in the index phase;
+//   * a row's end comes from its own pointer: the relation's `rowend` array when the batch is trimmed (PyG
+//     trim_to_layer, what every training step of the reference passes: models/analysis.py:960-961, models/cadence.py:
+//     167-173), `rowptr + 1` otherwise — the same two scalar loads either way, no branch;
+//   * all four rowptr / rowend pairs are one batch of scalar loads, all four column-id vectors one batch of vector
+//     loads, the first two neighbour rows of all four relations (8 loads; rows have ~1.6 neighbours per relation) one
 //     batch, and the 1/deg column scales of the backward pass travel with that batch;
 //   * nothing is stored before every gather of the row has been issued.
 // A row therefore costs rowptr -> col -> gather.  Loads are unconditional: lanes beyond the neighbour count repeat
 // the last neighbour (an L1 hit) or, for an empty segment, row 0, and what they fetch is dropped by a per-lane
 // select (not a multiply by zero: a non-finite value must not leak).  Neighbours beyond the second (rare) take the
 // two-at-a-time loop of k_spmm_fast.
+// FILT adds the two per-edge predicates of the C-ABI (column < col_limit: the backward pass of a trimmed layer;
+// column != row: the onset pooling, models/analysis.py:581-584).  They are evaluated once per column-id vector and kept
+// as a 64-bit wave mask in SGPRs: a neighbour's "keep" bit is a scalar shift, the valid count one s_bcnt1.
+// One row per wave: consecutive rows sharing one index phase measured slower (see launch_fast).
 // ------------------------------------------------------------------------------------------
 struct FastTable {
   const int32_t* rowptr[AGNN_MAX_SEG + 3];
+  const int32_t* rowend[AGNN_MAX_SEG + 3];     // per-row ends: the relation's rowend array, or rowptr + 1
   const int32_t* col[AGNN_MAX_SEG + 3];
   const float* src[AGNN_MAX_SEG + 3];
   const float* colscale[AGNN_MAX_SEG + 3];
@@ -349,40 +357,31 @@ __device__ __forceinline__ float4 f4_keep(bool keep, const float4& v) {
   return make_float4(keep ? v.x : 0.f, keep ? v.y : 0.f, keep ? v.z : 0.f, keep ? v.w : 0.f);
 }
 
-typedef const __attribute__((address_space(4))) float* k_f32p;
-
-template <int CH, int RPW, bool HAS_CS, bool SHARED, bool SELF>
-__global__ __launch_bounds__(256) void k_spmm_fast6(FastTable t, SpmmArgs a) {
+template <int CH, bool HAS_CS, bool SHARED, bool SELF, bool FILT>
+__global__ __launch_bounds__(256) void k_spmm_fast7(FastTable t, SpmmArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int vb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-contiguous row slabs
-  const int row0 = (vb * 4 + wave) * RPW;          // RPW consecutive rows per wave share the index phase
-  if (row0 >= a.n_rows) return;
+  const int row = vb * 4 + wave;
+  if (row >= a.n_rows) return;
   const bool mean = (a.flags & AGNN_SPMM_MEAN) != 0;
+  const bool skip_self = FILT && (a.flags & AGNN_SPMM_SKIP_SELF) != 0;
   const uint32_t loff = static_cast<uint32_t>(lane) * 16u;
-  int rowj[RPW];                                   // rows past the end repeat the last row for loads; never stored
-#pragma unroll
-  for (int j = 0; j < RPW; ++j) rowj[j] = row0 + j < a.n_rows ? row0 + j : a.n_rows - 1;
 
-  float4 selfv[SELF ? RPW : 1][SELF ? CH : 1];
+  float4 selfv[SELF ? CH : 1];
   if (SELF) {
+    const char* sp = reinterpret_cast<const char*>(a.self + static_cast<int64_t>(row) * a.ld_self);
 #pragma unroll
-    for (int j = 0; j < (SELF ? RPW : 1); ++j) {
-      const char* sp = reinterpret_cast<const char*>(a.self + static_cast<int64_t>(rowj[j]) * a.ld_self);
-#pragma unroll
-      for (int c = 0; c < (SELF ? CH : 1); ++c) selfv[j][c] = *reinterpret_cast<const float4*>(sp + (loff + c * 1024u));
-    }
+    for (int c = 0; c < (SELF ? CH : 1); ++c) selfv[c] = *reinterpret_cast<const float4*>(sp + (loff + c * 1024u));
   }
-  float4 tot[SHARED ? RPW : 1][SHARED ? CH : 1];
+  float4 tot[SHARED ? CH : 1];
 #pragma unroll
-  for (int j = 0; j < (SHARED ? RPW : 1); ++j)
-#pragma unroll
-    for (int c = 0; c < (SHARED ? CH : 1); ++c) tot[j][c] = f4_zero();
+  for (int c = 0; c < (SHARED ? CH : 1); ++c) tot[c] = f4_zero();
 
   for (int r0 = 0; r0 < t.n_rel; r0 += 4) {
-    // ---- index phase: no control flow; the empty asm statements pin "all pointers, then all rowptr entries, then
-    //      all column ids" (left alone, the compiler sinks each scalar load to its first use: one trip per relation)
-    k_i32p rpp[4];
+    // ---- index phase: no control flow; the empty asm statements pin "all pointers, then all rowptr / rowend entries,
+    //      then all column ids" (left alone, the compiler sinks each scalar load to its first use: one trip per relation)
+    k_i32p rpp[4], rep[4];
     const int32_t* cpp[4];
     const char* srcp[4];
     const float* csp[4];
@@ -390,197 +389,223 @@ __global__ __launch_bounds__(256) void k_spmm_fast6(FastTable t, SpmmArgs a) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       rpp[u] = (k_i32p)t.rowptr[r0 + u];
+      rep[u] = (k_i32p)t.rowend[r0 + u];
       cpp[u] = t.col[r0 + u];
       srcp[u] = reinterpret_cast<const char*>(t.src[r0 + u]);
       csp[u] = HAS_CS ? t.colscale[r0 + u] : nullptr;
       ldbv[u] = t.ldb[r0 + u];
     }
     asm volatile("" ::"s"(rpp[0]), "s"(rpp[1]), "s"(rpp[2]), "s"(rpp[3]), "s"(cpp[0]), "s"(cpp[1]), "s"(cpp[2]), "s"(cpp[3]));
+    asm volatile("" ::"s"(rep[0]), "s"(rep[1]), "s"(rep[2]), "s"(rep[3]));
     asm volatile("" ::"s"(srcp[0]), "s"(srcp[1]), "s"(srcp[2]), "s"(srcp[3]), "s"(ldbv[0]), "s"(ldbv[1]), "s"(ldbv[2]), "s"(ldbv[3]));
     if (HAS_CS) asm volatile("" ::"s"(csp[0]), "s"(csp[1]), "s"(csp[2]), "s"(csp[3]));
-    int ext[4][RPW + 1];                           // rowptr[row0 .. row0 + RPW], clamped to n_rows: rows past the end are empty
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int j = 0; j <= RPW; ++j) ext[u][j] = rpp[u][row0 + j < a.n_rows ? row0 + j : a.n_rows];
+    int beg[4], fin[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-#pragma unroll
-      for (int j = 0; j <= RPW; ++j) asm volatile("" ::"s"(ext[u][j]));
+      beg[u] = rpp[u][row];
+      fin[u] = rep[u][row];
     }
-    int n[RPW][4], off[RPW][4], span[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) asm volatile("" ::"s"(beg[u]), "s"(fin[u]));
+    int n[4], cntf[4];
     int colv[4];
     float wv[4];
+    uint64_t okm[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int live = r0 + u < t.n_rel ? -1 : 0;   // mask, not a branch: the tail entries of the table are valid duplicates
-#pragma unroll
-      for (int j = 0; j < RPW; ++j) {
-        n[j][u] = (ext[u][j + 1] - ext[u][j]) & live;
-        off[j][u] = ext[u][j] - ext[u][0];
-      }
-      span[u] = (ext[u][RPW] - ext[u][0]) & live;
+      n[u] = (fin[u] - beg[u]) & live;
       colv[u] = 0;
-      if (lane < span[u]) colv[u] = cpp[u][ext[u][0] + lane];
+      if (lane < n[u]) colv[u] = cpp[u][beg[u] + lane];
     }
-#define AGNN_OVF(j, u) (off[j][u] + n[j][u] > 64)  /* segment not (entirely) among the 64 ids held in registers */
-    // ---- row after row on the same registers: the index phase above is paid once per wave, a further row costs one
-    //      gather round trip
-#pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-      if (row0 + j >= a.n_rows) break;
-      // the first two neighbour rows of every relation
-      float4 v0[4][CH], v1[4][CH];
+    if (FILT) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const uint64_t ldb = ldbv[u];
-        const int p0 = off[j][u] < 63 ? off[j][u] : 63;
-        int step;                                  // 1 when the segment has >= 2 neighbours, else the second load repeats the first
-        asm("s_sub_i32 %0, 1, %1\n\ts_lshr_b32 %0, %0, 31" : "=s"(step) : "s"(n[j][u]) : "scc");
-        const int p1 = RPW == 1 ? step : (p0 + step < 63 ? p0 + step : 63);
-        const uint32_t c0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(colv[u], p0));
-        const uint32_t c1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(colv[u], p1));
-        const char* b0 = srcp[u] + c0 * ldb;       // column ids are non-negative: one s_mul + one s_mul_hi
-        const char* b1 = srcp[u] + c1 * ldb;
+        const bool ok = lane < n[u] && colv[u] < a.col_limit && !(skip_self && colv[u] == row);
+        okm[u] = __ballot(ok);
+        colv[u] = ok ? colv[u] : 0;               // dropped neighbours are fetched from row 0 and discarded
+        cntf[u] = 0;
+      }
+    }
+#define AGNN_OVF(u) (n[u] > 64)     /* segment not (entirely) among the 64 ids held in registers */
+#define AGNN_BIT(u, k) static_cast<int>((okm[u] >> (k)) & 1u)
+    // the first two neighbour rows of every relation
+    float4 v0[4][CH], v1[4][CH];
 #pragma unroll
-        for (int c = 0; c < CH; ++c) v0[u][c] = *reinterpret_cast<const float4*>(b0 + (loff + c * 1024u));
+    for (int u = 0; u < 4; ++u) {
+      const uint64_t ldb = ldbv[u];
+      int step;                                    // 1 when the segment has >= 2 neighbours, else the second load repeats the first
+      asm("s_sub_i32 %0, 1, %1\n\ts_lshr_b32 %0, %0, 31" : "=s"(step) : "s"(n[u]) : "scc");
+      const uint32_t c0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(colv[u], 0));
+      const uint32_t c1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(colv[u], step));
+      const char* b0 = srcp[u] + c0 * ldb;         // column ids are non-negative: one s_mul + one s_mul_hi
+      const char* b1 = srcp[u] + c1 * ldb;
 #pragma unroll
-        for (int c = 0; c < CH; ++c) v1[u][c] = *reinterpret_cast<const float4*>(b1 + (loff + c * 1024u));
-        if (HAS_CS && j == 0) {                    // the 1/deg scales travel with the first row's gathers
-          wv[u] = 0.f;
-          if (lane < span[u]) wv[u] = csp[u][colv[u]];
-        }
-        __builtin_amdgcn_sched_barrier(0);         // every gather is issued before the first one is waited for, and
-      }                                            // address registers are recycled from pair to pair
-      // reduce (in place: v0 becomes the accumulator)
+      for (int c = 0; c < CH; ++c) v0[u][c] = *reinterpret_cast<const float4*>(b0 + (loff + c * 1024u));
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int nv = to_vgpr(AGNN_OVF(j, u) ? 0 : n[j][u]);
-        float w0 = 1.f, w1 = 1.f;
+      for (int c = 0; c < CH; ++c) v1[u][c] = *reinterpret_cast<const float4*>(b1 + (loff + c * 1024u));
+      if (HAS_CS) {                                // the 1/deg scales travel with the gathers
+        wv[u] = 0.f;
+        if (lane < n[u]) wv[u] = csp[u][colv[u]];
+      }
+      __builtin_amdgcn_sched_barrier(0);           // every gather is issued before the first one is waited for, and
+    }                                              // address registers are recycled from pair to pair
+    // reduce (in place: v0 becomes the accumulator)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int k0s, k1s;
+      if (FILT) {
+        k0s = (AGNN_OVF(u) || n[u] < 1) ? 0 : AGNN_BIT(u, 0);
+        k1s = (AGNN_OVF(u) || n[u] < 2) ? 0 : AGNN_BIT(u, 1);
+      } else {
+        const int nvs = AGNN_OVF(u) ? 0 : n[u];
+        k0s = nvs > 0 ? 1 : 0;
+        k1s = nvs > 1 ? 1 : 0;
+      }
+      const int k0v = to_vgpr(k0s), k1v = to_vgpr(k1s);
+      float w0 = 1.f, w1 = 1.f;
+      if (HAS_CS) {
+        w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv[u]), 0));
+        w1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv[u]), 1));
+      }
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const float4 k0 = f4_keep(k0v != 0, v0[u][c]), k1 = f4_keep(k1v != 0, v1[u][c]);
         if (HAS_CS) {
-          const int p0 = off[j][u] < 63 ? off[j][u] : 63;
-          w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv[u]), p0));
-          w1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv[u]), p0 < 63 ? p0 + 1 : 63));
-        }
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          const float4 k0 = f4_keep(nv > 0, v0[u][c]), k1 = f4_keep(nv > 1, v1[u][c]);
-          if (HAS_CS) {
-            v0[u][c] = make_float4(w0 * k0.x, w0 * k0.y, w0 * k0.z, w0 * k0.w);
-            f4_fma(v0[u][c], w1, k1);
-          } else {
-            v0[u][c] = make_float4(k0.x + k1.x, k0.y + k1.y, k0.z + k1.z, k0.w + k1.w);
-          }
+          v0[u][c] = make_float4(w0 * k0.x, w0 * k0.y, w0 * k0.z, w0 * k0.w);
+          f4_fma(v0[u][c], w1, k1);
+        } else {
+          v0[u][c] = make_float4(k0.x + k1.x, k0.y + k1.y, k0.z + k1.z, k0.w + k1.w);
         }
       }
-      // third and later neighbours (and segments whose ids are not in registers), two at a time
+    }
+    // third and later neighbours (and segments whose ids are not in registers), two at a time
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int nn = n[j][u];
-        if (nn > 2 || AGNN_OVF(j, u)) {
-          const uint64_t ldb = ldbv[u];
-          const bool in_regs = !AGNN_OVF(j, u);
-          const k_i32p colg = (k_i32p)cpp[u] + ext[u][j];
-          for (int k = in_regs ? 2 : 0; k < nn; k += 2) {
-            const bool two = k + 1 < nn;
-            const int ka = k, kb = two ? k + 1 : k;
-            uint32_t c0, c1;
-            float x0 = 1.f, x1 = 1.f;
-            if (in_regs) {
-              c0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(colv[u], off[j][u] + ka));
-              c1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(colv[u], off[j][u] + kb));
-              if (HAS_CS) {
-                x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv[u]), off[j][u] + ka));
-                x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv[u]), off[j][u] + kb));
-              }
-            } else {                               // > 64 neighbours in the wave's rows of this relation: scalar loads
-              c0 = static_cast<uint32_t>(colg[ka]);
-              c1 = static_cast<uint32_t>(colg[kb]);
-              if (HAS_CS) {
-                x0 = ((k_f32p)csp[u])[c0];
-                x1 = ((k_f32p)csp[u])[c1];
-              }
+    for (int u = 0; u < 4; ++u) {
+      const int nn = n[u];
+      if (nn > 2 || AGNN_OVF(u)) {
+        const uint64_t ldb = ldbv[u];
+        const bool in_regs = !AGNN_OVF(u);
+        const k_i32p colg = (k_i32p)cpp[u] + beg[u];
+        for (int k = in_regs ? 2 : 0; k < nn; k += 2) {
+          const bool two = k + 1 < nn;
+          const int ka = k, kb = two ? k + 1 : k;
+          uint32_t c0, c1;
+          float x0 = 1.f, x1 = 1.f;
+          int keep0 = 1, keep1 = two ? 1 : 0;
+          if (in_regs) {
+            c0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(colv[u], ka));
+            c1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(colv[u], kb));
+            if (HAS_CS) {
+              x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv[u]), ka));
+              x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv[u]), kb));
             }
-            const char* b0 = srcp[u] + c0 * ldb;
-            const char* b1 = srcp[u] + c1 * ldb;
-            float4 q0[CH], q1[CH];
+            if (FILT) {
+              keep0 = AGNN_BIT(u, ka);
+              keep1 &= AGNN_BIT(u, kb);
+            }
+          } else {                               // > 64 neighbours in this row of this relation: scalar loads
+            c0 = static_cast<uint32_t>(colg[ka]);
+            c1 = static_cast<uint32_t>(colg[kb]);
+            if (FILT) {
+              const int i0 = static_cast<int>(c0), i1 = static_cast<int>(c1);
+              keep0 = (i0 < a.col_limit && !(skip_self && i0 == row)) ? 1 : 0;
+              keep1 &= (i1 < a.col_limit && !(skip_self && i1 == row)) ? 1 : 0;
+              c0 = keep0 ? c0 : 0u;
+              c1 = keep1 ? c1 : 0u;
+              cntf[u] += keep0 + keep1;
+            }
+            if (HAS_CS) {
+              x0 = ((k_f32p)csp[u])[c0];
+              x1 = ((k_f32p)csp[u])[c1];
+            }
+          }
+          const char* b0 = srcp[u] + c0 * ldb;
+          const char* b1 = srcp[u] + c1 * ldb;
+          float4 q0[CH], q1[CH];
 #pragma unroll
-            for (int c = 0; c < CH; ++c) q0[c] = *reinterpret_cast<const float4*>(b0 + (loff + c * 1024u));
+          for (int c = 0; c < CH; ++c) q0[c] = *reinterpret_cast<const float4*>(b0 + (loff + c * 1024u));
 #pragma unroll
-            for (int c = 0; c < CH; ++c) q1[c] = *reinterpret_cast<const float4*>(b1 + (loff + c * 1024u));
-            const int twov = to_vgpr(two ? 1 : 0);
+          for (int c = 0; c < CH; ++c) q1[c] = *reinterpret_cast<const float4*>(b1 + (loff + c * 1024u));
+          const int k1v = to_vgpr(keep1);
+          if (FILT) {
+            const int k0v = to_vgpr(keep0);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+              f4_fma(v0[u][c], x0, f4_keep(k0v != 0, q0[c]));
+              f4_fma(v0[u][c], x1, f4_keep(k1v != 0, q1[c]));
+            }
+          } else {
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
               f4_fma(v0[u][c], x0, q0[c]);
-              f4_fma(v0[u][c], x1, f4_keep(twov != 0, q1[c]));
+              f4_fma(v0[u][c], x1, f4_keep(k1v != 0, q1[c]));
             }
           }
         }
       }
-      // scale and store.  1 / max(count, 1) of the four relations is computed once, in lanes 0..3 (v_rcp_f32, <= 1 ulp),
-      // stored by those lanes with one instruction and broadcast back as scalars.
-      int nvec = 1;
+    }
+    // scale and store.  1 / max(count, 1) of the four relations is computed once, in lanes 0..3 (v_rcp_f32, <= 1 ulp),
+    // stored by those lanes with one instruction and broadcast back as scalars.
+    int nvec = 1;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int cnt = n[j][u] > 1 ? n[j][u] : 1;
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(nvec) : "s"(cnt), "n"(u));
+    for (int u = 0; u < 4; ++u) {
+      int cnt = n[u];
+      if (FILT) cnt = __builtin_amdgcn_readfirstlane(AGNN_OVF(u) ? cntf[u] : __builtin_popcountll(okm[u]));
+      cnt = cnt > 1 ? cnt : 1;
+      asm("v_writelane_b32 %0, %1, %2" : "+v"(nvec) : "s"(cnt), "n"(u));
+    }
+    const float invv = __builtin_amdgcn_rcpf(static_cast<float>(nvec));
+    if (a.inv_cnt != nullptr && lane < 4 && r0 + lane < t.n_rel)
+      a.inv_cnt[static_cast<int64_t>(r0 + lane) * a.n_rows + row] = invv;
+    const float scalev = mean ? invv : 1.f;      // sums: x * 1.f is exact
+    char* op = reinterpret_cast<char*>(a.out + static_cast<int64_t>(row) * a.ld_out + static_cast<int64_t>(r0) * a.rel_stride) + loff;
+    const int64_t op_step = a.rel_stride * 4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (r0 + u >= t.n_rel) break;
+      const float inv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(scalev), u));
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        float4& o = v0[u][c];
+        if (SELF) f4_add(o, selfv[SELF ? c : 0]);
+        o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
       }
-      const float invv = __builtin_amdgcn_rcpf(static_cast<float>(nvec));
-      if (a.inv_cnt != nullptr && lane < 4 && r0 + lane < t.n_rel)
-        a.inv_cnt[static_cast<int64_t>(r0 + lane) * a.n_rows + (row0 + j)] = invv;
-      const float scalev = mean ? invv : 1.f;      // sums: x * 1.f is exact
-      char* op = reinterpret_cast<char*>(a.out + static_cast<int64_t>(row0 + j) * a.ld_out + static_cast<int64_t>(r0) * a.rel_stride) + loff;
-      const int64_t op_step = a.rel_stride * 4;
+      if (SHARED) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (r0 + u >= t.n_rel) break;
-        const float inv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(scalev), u));
+        for (int c = 0; c < CH; ++c) f4_add(tot[SHARED ? c : 0], v0[u][c]);
+      } else {
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          float4& o = v0[u][c];
-          if (SELF) f4_add(o, selfv[SELF ? j : 0][SELF ? c : 0]);
-          o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
-        }
-        if (SHARED) {
-#pragma unroll
-          for (int c = 0; c < CH; ++c) f4_add(tot[SHARED ? j : 0][SHARED ? c : 0], v0[u][c]);
-        } else {
-#pragma unroll
-          for (int c = 0; c < CH; ++c) *reinterpret_cast<float4*>(op + c * 1024) = v0[u][c];
-          op += op_step;
-        }
+        for (int c = 0; c < CH; ++c) *reinterpret_cast<float4*>(op + c * 1024) = v0[u][c];
+        op += op_step;
       }
     }
 #undef AGNN_OVF
+#undef AGNN_BIT
   }
   if (SHARED) {
+    char* op = reinterpret_cast<char*>(a.out + static_cast<int64_t>(row) * a.ld_out);
 #pragma unroll
-    for (int j = 0; j < (SHARED ? RPW : 1); ++j) {
-      if (row0 + j >= a.n_rows) break;
-      char* op = reinterpret_cast<char*>(a.out + static_cast<int64_t>(row0 + j) * a.ld_out);
-#pragma unroll
-      for (int c = 0; c < CH; ++c) *reinterpret_cast<float4*>(op + (loff + c * 1024u)) = tot[j][SHARED ? c : 0];
-    }
+    for (int c = 0; c < CH; ++c) *reinterpret_cast<float4*>(op + (loff + c * 1024u)) = tot[SHARED ? c : 0];
   }
 }
 
 template <int CH>
-void launch_fast(hipStream_t stream, const RelTable& t, const SpmmArgs& a, bool has_cs) {
+void launch_fast(hipStream_t stream, const RelTable& t, const SpmmArgs& a, bool has_cs, bool filt) {
   const bool shared = a.rel_stride == 0, self = a.self != nullptr;
   const bool v4 = (a.flags & AGNN_SPMM_FAST_V4) != 0 || (a.flags & AGNN_SPMM_ACCUM) != 0;
-  // Rows per wave.  More than one (consecutive rows sharing one index phase) measured SLOWER at the C2 shape, both with
-  // the rows' gathers in flight together (95 VGPRs -> 5 waves / SIMD: forward 17.1 us vs 15.5 us) and one row after
+  // Rows per wave: one.  More than one (consecutive rows sharing one index phase) measured SLOWER at the C2 shape, both
+  // with the rows' gathers in flight together (95 VGPRs -> 5 waves / SIMD: forward 17.1 us vs 15.5 us) and one row after
   // the other on the same registers (16.5 us; backward 18.1 vs 15.5 us): vmcnt counts in issue order, so the second
   // row's gathers cannot be consumed before the first row's stores are acknowledged, whereas a wave that ends after
-  // its stores hands its slot to a new wave at once.  The kernel keeps the RPW parameter; only 1 is instantiated.
-  constexpr int rpw = 1;
-  const int rows_per_block = 4 * rpw;
-  const dim3 grid(static_cast<unsigned>(((a.n_rows + rows_per_block - 1) / rows_per_block + 7) & ~7));   // multiple of 8: the XCD remap is a bijection
+  // its stores hands its slot to a new wave at once (round 1, profiles/r01_spmm_kernel_study.md).
+  const dim3 grid(static_cast<unsigned>(((a.n_rows + 3) / 4 + 7) & ~7));   // multiple of 8: the XCD remap is a bijection
   FastTable f{};
   f.n_rel = t.n_rel;
   for (int r = 0; r < AGNN_MAX_SEG + 3; ++r) {
     const agnn_rel_t& R = t.r[r < t.n_rel ? r : t.n_rel - 1];     // the tail repeats the last relation: loads stay valid
     f.rowptr[r] = R.rowptr;
+    f.rowend[r] = R.rowend != nullptr ? R.rowend : R.rowptr + 1;   // untrimmed: row i ends where row i + 1 starts
     f.col[r] = R.col;
     f.src[r] = R.src;
     f.colscale[r] = R.colscale;
@@ -589,7 +614,8 @@ void launch_fast(hipStream_t stream, const RelTable& t, const SpmmArgs& a, bool 
 #define AGNN_FAST(CS, SH, SE)                                                                                     \
   do {                                                                                                            \
     if (v4) hipLaunchKernelGGL((k_spmm_fast<CH, CS, SH, SE>), grid, dim3(256), 0, stream, t, a);                  \
-    else hipLaunchKernelGGL((k_spmm_fast6<CH, rpw, CS, SH, SE>), grid, dim3(256), 0, stream, f, a);               \
+    else if (filt) hipLaunchKernelGGL((k_spmm_fast7<CH, CS, SH, SE, true>), grid, dim3(256), 0, stream, f, a);    \
+    else hipLaunchKernelGGL((k_spmm_fast7<CH, CS, SH, SE, false>), grid, dim3(256), 0, stream, f, a);             \
   } while (0)
   if (has_cs) {
     if (shared && self) AGNN_FAST(true, true, true); else if (shared) AGNN_FAST(true, true, false);
@@ -672,18 +698,21 @@ extern "C" int agnn_spmm_f32(int n_rel, const agnn_rel_t* rels, int64_t n_rows, 
   SpmmArgs a{static_cast<int32_t>(n_rows), H, out, ld_out, rel_stride, self, ld_self, inv_cnt, col_limit, flags};
   int64_t blocks = ((n_rows + 3) / 4 + 7) & ~int64_t{7};   // multiple of 8: the XCD remap is a bijection
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (!(flags & AGNN_SPMM_GENERIC) && (H == 256 || H == 512) && !(flags & AGNN_SPMM_SKIP_SELF) &&
-      col_limit == INT32_MAX) {
+  if (!(flags & AGNN_SPMM_GENERIC) && (H == 256 || H == 512)) {
+    // fast path: everything except per-edge weights; trimmed rows (rowend) cost nothing extra, the per-edge predicates
+    // (SKIP_SELF, col_limit) select the FILT instantiation; the older v4 kernel (ACCUM, A/B timing) knows neither
+    const bool filt = (flags & AGNN_SPMM_SKIP_SELF) != 0 || col_limit != INT32_MAX;
+    const bool v4 = (flags & (AGNN_SPMM_FAST_V4 | AGNN_SPMM_ACCUM)) != 0;
     bool plain = true, any_cs = false, all_cs = true;
     for (int r = 0; r < n_rel; ++r) {
-      plain = plain && rels[r].rowend == nullptr && rels[r].ew == nullptr && rels[r].src != nullptr && rels[r].col != nullptr &&
-              rels[r].ld_src < (int64_t{1} << 30);
+      plain = plain && rels[r].ew == nullptr && rels[r].src != nullptr && rels[r].col != nullptr &&
+              rels[r].ld_src < (int64_t{1} << 30) && !(v4 && rels[r].rowend != nullptr);
       any_cs = any_cs || rels[r].colscale != nullptr;
       all_cs = all_cs && rels[r].colscale != nullptr;
     }
-    if (plain && any_cs == all_cs) {
-      if (H == 256) launch_fast<1>(stream, t, a, all_cs);
-      else launch_fast<2>(stream, t, a, all_cs);
+    if (plain && any_cs == all_cs && !(v4 && filt)) {
+      if (H == 256) launch_fast<1>(stream, t, a, all_cs, filt);
+      else launch_fast<2>(stream, t, a, all_cs, filt);
       return check_launch("spmm(fast)");
     }
   }

@@ -165,6 +165,7 @@ class HeteroSAGEStack(nn.Module):
     def forward(self, x_dict, edge_index_dict, plan: TrimPlan, collect: Optional[list] = None):
         index = hetero_index(edge_index_dict, {k: int(v.shape[0]) for k, v in x_dict.items()})
         self.last_index = index          # reused by the onset pooling that follows the encoder (models.py)
+        index.prepare_trim(plan.e_keep)  # sampled batch: the row ends of all trimmed layers in one launch
         for i, conv in enumerate(self.convs):
             keep = plan.n_keep[i]
             x_dict = {k: v for k, v in x_dict.items()}

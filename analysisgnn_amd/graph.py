@@ -127,6 +127,37 @@ class HeteroIndex:
         self.bwd: Dict[EdgeType, Csr] = {et: csrs[n + i] for i, et in enumerate(self.edge_types)}
 
 
+    def prepare_trim(self, e_keep_layers: Sequence[Dict[EdgeType, Optional[int]]]) -> None:
+        """Row ends of every relation, in both directions, for every COO prefix the layers of a trimmed (sampled) batch
+        keep (PyG trim_to_layer, reference models/cadence.py:165-173) — ONE launch (`agnn_csr_rowend_batch`) instead of
+        one per (relation, direction, layer) on first use.  Fills the `Csr.rowend` caches."""
+        todo = []
+        for e_keep in e_keep_layers:
+            for et, lim in e_keep.items():
+                if lim is None or et not in self.fwd:
+                    continue
+                for csr in (self.fwd[et], self.bwd[et]):
+                    if lim < csr.n_edges and lim not in csr._rowend and csr.n_rows > 0 and not any(
+                            c is csr and l == lim for c, l in todo):
+                        todo.append((csr, int(lim)))
+        if not todo:
+            return
+        lib = _lib.load()
+        dev = todo[0][0].rowptr.device
+        buf = torch.empty(sum(c.n_rows for c, _ in todo), dtype=torch.int32, device=dev)
+        base = 0
+        for i in range(0, len(todo), _lib.ROWEND_MAX_ITEMS):
+            chunk = todo[i:i + _lib.ROWEND_MAX_ITEMS]
+            items = (_lib.RowendItem * len(chunk))()
+            for j, (csr, lim) in enumerate(chunk):
+                out = buf[base:base + csr.n_rows]
+                base += csr.n_rows
+                items[j].rowptr, items[j].perm, items[j].rowend = csr.rowptr.data_ptr(), csr.perm.data_ptr(), out.data_ptr()
+                items[j].n_rows, items[j].e_limit = csr.n_rows, lim
+                csr._rowend[lim] = out
+            _lib.check(lib.agnn_csr_rowend_batch(len(chunk), items, _lib.stream_ptr(dev)), "agnn_csr_rowend_batch")
+
+
 _INDEX_CACHE: "Dict[tuple, HeteroIndex]" = {}
 _INDEX_CACHE_MAX = 8
 index_cache_enabled = True

@@ -128,7 +128,7 @@ class _MultiTaskCE(torch.autograd.Function):
             logits = logits.float().contiguous()
         N = logits.shape[0]
         T = offs_t.numel() - 1
-        labels = labels.contiguous()
+        labels = _check_labels(labels, T, N)
         row_loss = torch.empty((T, N), dtype=torch.float32, device=dev)
         loss = torch.zeros((T,), dtype=torch.float32, device=dev)
         inv_cnt = torch.ones((T,), dtype=torch.float32, device=dev)
@@ -167,12 +167,21 @@ _OFFS_CACHE: Dict[tuple, torch.Tensor] = {}
 _LOSS_WS: Dict[str, torch.Tensor] = {}
 
 
+def _check_labels(labels: torch.Tensor, T: int, N: int) -> torch.Tensor:
+    """The kernels read labels as int64 [T, N]; anything else would be reinterpreted, not converted."""
+    if labels.dtype != torch.int64:
+        raise _lib.AgnnError(f"labels must be int64 (torch.long), got {labels.dtype}")
+    if tuple(labels.shape) != (T, N):
+        raise _lib.AgnnError(f"labels must have shape [T={T}, N={N}] (one row per task), got {tuple(labels.shape)}")
+    return labels.contiguous()
+
+
 class _TrainLoss(torch.autograd.Function):
-    """total = sum_t CE_t + lam * mean(feat^2) (agnn_train_loss_f32: two launches) and its gradient w.r.t. the logits and
-    feat (agnn_train_loss_bwd_f32: one launch)."""
+    """total = ce_scale * sum_t (w_t CE_t + reg_t) + lam * mean(feat^2) (agnn_train_loss_f32: two launches) and its gradient
+    w.r.t. the logits, feat (agnn_train_loss_bwd_f32: one launch) and the task weights p (one tiny multiply)."""
 
     @staticmethod
-    def forward(ctx, logits, labels, offs_t, feat, eps: float, ignore_index: int, lam: float):
+    def forward(ctx, logits, labels, offs_t, feat, task_param, eps: float, ignore_index: int, lam: float, ce_scale: float):
         dev = _lib.require_gpu(logits, labels, offs_t, feat)
         if logits.dtype != torch.float32 or logits.stride(1) != 1:
             logits = logits.float().contiguous()
@@ -180,22 +189,30 @@ class _TrainLoss(torch.autograd.Function):
             feat = feat.float().contiguous()
         N = logits.shape[0]
         T = offs_t.numel() - 1
-        labels = labels.contiguous()
+        labels = _check_labels(labels, T, N)
+        tp = None
+        if task_param is not None:
+            tp = task_param.detach().to(torch.float32).contiguous()
+            if tp.numel() != T:
+                raise _lib.AgnnError(f"task_param must have {T} entries, got {tp.numel()}")
         lib = _lib.load()
         ws = _LOSS_WS.get(str(dev))                           # one per device: calls on one device are assumed not to overlap
         if ws is None:                                        # zero-filled once; every call leaves it zero-filled
             ws = _LOSS_WS[str(dev)] = torch.zeros(int(lib.agnn_train_loss_workspace_bytes()) + 256, dtype=torch.uint8, device=dev)
         wsp = (ws.data_ptr() + 255) & ~255
         row_loss = torch.empty((T, N), dtype=torch.float32, device=dev)
-        out = torch.empty((2 * T + 1,), dtype=torch.float32, device=dev)      # loss[T] | inv_cnt[T] | total
+        out = torch.empty((4 * T + 1,), dtype=torch.float32, device=dev)      # loss[T] | inv_cnt[T] | total | wscale[T] | dparam[T]
         dlogits = torch.empty_like(logits)
         _lib.check(lib.agnn_train_loss_f32(logits.data_ptr(), logits.stride(0), offs_t.data_ptr(), T, labels.data_ptr(), N, float(eps),
                                            int(ignore_index), feat.data_ptr(), feat.stride(0), feat.shape[1], float(lam),
-                                           row_loss.data_ptr(), dlogits.data_ptr(), out.data_ptr(), out[T:].data_ptr(),
-                                           out[2 * T:].data_ptr(), wsp, int(lib.agnn_train_loss_workspace_bytes()),
+                                           _lib.ptr(tp), float(ce_scale), row_loss.data_ptr(), dlogits.data_ptr(), out.data_ptr(),
+                                           out[T:].data_ptr(), out[2 * T:].data_ptr(), out[2 * T + 1:].data_ptr(),
+                                           out[3 * T + 1:].data_ptr(), wsp, int(lib.agnn_train_loss_workspace_bytes()),
                                            _lib.stream_ptr(dev)), "agnn_train_loss_f32")
         ctx.save_for_backward(dlogits, offs_t, out, feat)
         ctx.lam = float(lam)
+        ctx.T = T
+        ctx.has_param = task_param is not None
         ctx.mark_non_differentiable(out)
         ctx.set_materialize_grads(False)                      # no zero-filled gradient for the logging output
         return out[2 * T], out
@@ -204,29 +221,80 @@ class _TrainLoss(torch.autograd.Function):
     def backward(ctx, g, _g_parts):
         dlogits, offs_t, out, feat = ctx.saved_tensors
         dev = dlogits.device
-        T = offs_t.numel() - 1
+        T = ctx.T
         g = g.to(torch.float32).contiguous()
         dl = torch.empty_like(dlogits)
         dfeat = torch.empty_like(feat) if ctx.needs_input_grad[3] else None
         lib = _lib.load()
         _lib.check(lib.agnn_train_loss_bwd_f32(dlogits.data_ptr(), dlogits.stride(0), offs_t.data_ptr(), T, dlogits.shape[0],
-                                               dlogits.shape[1], out[T:].data_ptr(), g.data_ptr(), dl.data_ptr(), dl.stride(0),
+                                               dlogits.shape[1], out[2 * T + 1:].data_ptr(), g.data_ptr(), dl.data_ptr(), dl.stride(0),
                                                feat.data_ptr(), feat.stride(0), feat.shape[1], ctx.lam, _lib.ptr(dfeat),
                                                dfeat.stride(0) if dfeat is not None else 0, _lib.stream_ptr(dev)),
                    "agnn_train_loss_bwd_f32")
-        return dl, None, None, dfeat, None, None, None
+        dparam = out[3 * T + 1:4 * T + 1] * g if (ctx.has_param and ctx.needs_input_grad[4]) else None
+        return dl, None, None, dfeat, dparam, None, None, None, None
+
+
+class MultiTaskLoss(nn.Module):
+    """The reference's task-weighting module (models/chord.py:16-49): one learned uncertainty weight per task,
+    `params` initialised to ones (same parameter name, so a reference state_dict / optimizer group maps by name).
+    `requires_grad=False` is the plain sum (mt_strategy other than 'wloss', models/analysis.py:904-908).  The weighting itself
+    runs inside `agnn_train_loss_f32` (heads.training_loss); `forward` accepts the reference's dict arguments."""
+
+    def __init__(self, tasks: Sequence[str], loss_ft=None, loss_weights=None, requires_grad: bool = True):
+        super().__init__()
+        self.tasks = list(tasks)
+        self.requires_grad = bool(requires_grad)
+        if self.requires_grad:
+            self.params = nn.Parameter(torch.ones(len(self.tasks)))
+        else:
+            self.register_buffer("params", torch.ones(len(self.tasks)), persistent=False)
+
+    def weights(self) -> Optional[torch.Tensor]:
+        return self.params if self.requires_grad else None
+
+    def forward(self, pred: Dict[str, torch.Tensor], gt: Dict[str, torch.Tensor], label_smoothing: float = 0.1,
+                ignore_index: int = -1) -> Dict[str, torch.Tensor]:
+        """pred / gt dicts as at models/analysis.py:1034: per-task losses plus "total" (the weighted sum, NOT yet divided
+        by the number of tasks — the caller does that, :1036).  Tasks are weighted by their position in `gt`
+        (models/chord.py:41-44 enumerates `out.values()`)."""
+        tasks = list(gt.keys())
+        logits = torch.cat([pred[t] for t in tasks], dim=1)
+        offs = [0]
+        for t in tasks:
+            offs.append(offs[-1] + pred[t].shape[1])
+        labels = torch.stack([gt[t] for t in tasks])
+        per = multitask_cross_entropy(logits, offs, labels, label_smoothing, ignore_index)
+        out = {t: per[i] for i, t in enumerate(tasks)}
+        if self.requires_grad:
+            p = self.params[:len(tasks)]
+            out["total"] = (0.5 / p ** 2 * per + torch.log(1 + p ** 2)).sum()
+        else:
+            out["total"] = per.sum()
+        return out
 
 
 def training_loss(logits: torch.Tensor, offs: Sequence[int], labels: torch.Tensor, feat: torch.Tensor, lambda_feat: float = 0.1,
-                  label_smoothing: float = 0.1, ignore_index: int = -1) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(total, per_task) with total = sum_t CrossEntropy_t + lambda_feat * feat.pow(2).mean() — the reference's training
-    objective without its optional terms (models/analysis.py:881-888, :984, :1072) — in two launches forward and one
-    backward.  per_task [T] are the mean losses per task (for logging; not differentiable).  Requires segments that
-    cover the logits' columns side by side (what fused_head_logits produces)."""
+                  label_smoothing: float = 0.1, ignore_index: int = -1, task_params: Optional[torch.Tensor] = None,
+                  ce_scale: Optional[float] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(total, per_task): the reference's training objective without its optional (continual-learning, edge) terms,
+        total = ce_scale * sum_t (w_t CE_t + reg_t) + lambda_feat * feat.pow(2).mean(),     ce_scale = 1 / T by default
+    (models/analysis.py:1034-1036 `loss_dict.pop("total") / len(labels_dict)`, :984, :1072); with `task_params` (the `params`
+    of `MultiTaskLoss`, --mt_strategy wloss) w_t = 0.5 / p_t^2 and reg_t = log(1 + p_t^2) (models/chord.py:39-49), otherwise
+    w_t = 1, reg_t = 0 — in two launches forward and one backward.  per_task [T] are the mean cross entropies per task (for
+    logging; not differentiable).  A task whose labels are all `ignore_index` contributes 0 (torch: NaN); a label outside
+    [0, C_t) that is not `ignore_index` makes total and gradients NaN (torch: device assert).  Requires segments that cover
+    the logits' columns side by side (what fused_head_logits produces)."""
+    T = len(offs) - 1
+    scale = (1.0 / T) if ce_scale is None else float(ce_scale)
     full = len(offs) > 1 and offs[0] == 0 and offs[-1] == logits.shape[1] and all(offs[i] < offs[i + 1] for i in range(len(offs) - 1))
     if not full:
         per_task = multitask_cross_entropy(logits, offs, labels, label_smoothing, ignore_index)
-        return per_task.sum() + lambda_feat * feat.pow(2).mean(), per_task.detach()
-    total, out = _TrainLoss.apply(logits, labels, _offs_tensor(offs, logits.device), feat, label_smoothing, ignore_index, lambda_feat)
-    return total, out[:len(offs) - 1]
-
+        if task_params is not None:
+            ce = (0.5 / task_params ** 2 * per_task + torch.log(1 + task_params ** 2)).sum()
+        else:
+            ce = per_task.sum()
+        return scale * ce + lambda_feat * feat.pow(2).mean(), per_task.detach()
+    total, out = _TrainLoss.apply(logits, labels, _offs_tensor(offs, logits.device), feat, task_params, label_smoothing,
+                                  ignore_index, lambda_feat, scale)
+    return total, out[:T]

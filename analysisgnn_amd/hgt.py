@@ -327,6 +327,7 @@ class HeteroHGTStack(nn.Module):
 
     def forward(self, x_dict, edge_index_dict, plan: TrimPlan, collect: Optional[list] = None):
         index = hetero_index(edge_index_dict, {k: int(v.shape[0]) for k, v in x_dict.items()})
+        index.prepare_trim(plan.e_keep)
         self.last_index = index
         for i, conv in enumerate(self.convs):
             x_dict = conv(x_dict, edge_index_dict, index, plan.n_keep[i], plan.e_keep[i])
@@ -358,3 +359,38 @@ class HybridHGT(nn.Module, _HybridMixin):
         h = self.gnn(x_dict, edge_index_dict, plan, outs)
         out = self._finish(h["note"], outs, z, side, batch_size)
         return (out, edge_index_dict) if return_edge_index else out
+
+
+def attention_roofline_case(g, I, hid: int, dev, timed, hbm_peak: float, heads: int = 4) -> dict:
+    """bench.py's `roofline` object for the HGT workload (C3): the forward edge-softmax attention launch of the note
+    destination type (the relations that end in `note`), same CSR and shapes as in the step, timed by `timed`.
+    ALGORITHMIC bytes per launch: per relation the CSR (4 (N_dst + 1) + 4 E_r) and every distinct K', V' row once
+    (2 * 4 H * N_src_unique_r: K' and V' are relation-specific), plus q and the output once (2 * 4 H * N_dst) and the
+    softmax statistics kept for backward (2 * 4 * heads * N_dst)."""
+    import numpy as np
+    n_nodes = {k: int(v.shape[0]) for k, v in I["x_dict"].items()}
+    hix = HeteroIndex(I["edge_index_dict"], n_nodes)
+    ets = [et for et in hix.edge_types if et[2] == "note"]
+    n = n_nodes["note"]
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    q = torch.randn(n, hid, generator=gen).to(dev)
+    kv = []
+    for et in ets:
+        kv += [torch.randn(n_nodes[et[0]], hid, generator=gen).to(dev), torch.randn(n_nodes[et[0]], hid, generator=gen).to(dev)]
+    ps = torch.full((len(ets), heads), 1.0 / math.sqrt(hid // heads), device=dev)
+    spec = _AttnSpec(fwd=[hix.fwd[et] for et in ets], bwd=[hix.bwd[et] for et in ets], n_rows=n, heads=heads,
+                     n_edges=[hix.num_edges[et] for et in ets], e_limit=None, src_rows=[n_nodes[et[0]] for et in ets])
+    with torch.no_grad():
+        t_k, launches = timed(lambda: _HGTAttention.apply(spec, q, ps, *kv))
+    b_alg, e_tot = 0, 0
+    for et in ets:
+        ei = g.edge_index[et]
+        e_tot += int(ei.shape[1])
+        b_alg += 4 * (n + 1) + 4 * int(ei.shape[1]) + 2 * 4 * hid * int(np.unique(ei[0]).size)
+    b_alg += 2 * 4 * hid * n + 2 * 4 * heads * n
+    return {"bound": "hbm",
+            "kernel": f"k_hgt_fwd forward edge-softmax attention of the note type (R={len(ets)}, N_dst={n}, E={e_tot}, H={hid}, heads={heads})",
+            "achieved": b_alg / t_k / 1e9, "peak": hbm_peak / 1e9, "unit": "GB/s", "frac": (b_alg / t_k) / hbm_peak,
+            "traffic": None, "traffic_source": "profiles/r02_hgt_pmc.md (rocprofv3 --pmc passes of this launch)",
+            "alg_bytes_per_launch": b_alg, "avg_us": t_k * 1e6, "launches": launches,
+            "timing": "HIP events around hipGraph replays of 10 back-to-back launches"}

@@ -180,16 +180,18 @@ def collate(graphs: Sequence[ScoreGraph]) -> ScoreGraph:
         num_graphs=len(graphs), batch_size=int(offs["note"]))
 
 
-def make_batch(n_graphs: int, n_notes: int = 500, first_seed: int = 0, **kw) -> ScoreGraph:
-    """Batch of ``n_graphs`` subgraphs with seeds first_seed .. first_seed+n_graphs-1."""
-    return collate([make_score_graph(seed=first_seed + i, n_notes=n_notes, **kw) for i in range(n_graphs)])
+def make_batch(n_graphs: int, n_notes: int = 500, first_seed: int = 0, seeds: Optional[Sequence[int]] = None, **kw) -> ScoreGraph:
+    """Batch of ``n_graphs`` subgraphs with seeds first_seed .. first_seed+n_graphs-1 (or the given ``seeds``: a
+    data-parallel rank's share {i : i mod G = rank} of the global batch, dp.shard_units)."""
+    seeds = list(seeds) if seeds is not None else [first_seed + i for i in range(n_graphs)]
+    return collate([make_score_graph(seed=sd, n_notes=n_notes, **kw) for sd in seeds])
 
 
 def sample_hops(g: ScoreGraph, n_targets: int, num_neighbors: Sequence[int], seed: int = 0,
-                random_targets: bool = False) -> ScoreGraph:
+                random_targets: bool = False, first_target: int = 0) -> ScoreGraph:
     """Neighbour-sampled view of a single note-only graph in PyG NeighborLoader layout.
 
-    Targets are the first ``n_targets`` notes (a window, as MuseNeighborLoader takes —
+    Targets are the ``n_targets`` notes from ``first_target`` on (a window, as MuseNeighborLoader takes —
     reference datamodules/analysis.py:270-278); hop h samples up to ``num_neighbors[h]``
     in-neighbours per relation for every node of hop h.  Nodes are hop-ordered, edges are
     hop-ordered per relation, ``num_sampled_nodes/edges`` hold per-hop counts exactly as
@@ -199,7 +201,7 @@ def sample_hops(g: ScoreGraph, n_targets: int, num_neighbors: Sequence[int], see
     rng = np.random.default_rng(seed)
     n = g.num_nodes["note"]
     order = (sorted(rng.choice(n, size=n_targets, replace=False).tolist()) if random_targets
-             else list(range(n_targets)))
+             else list(range(first_target, first_target + n_targets)))
     pos = {v: i for i, v in enumerate(order)}
     nodes_per_hop = [n_targets]
     in_lists = {}
@@ -241,6 +243,67 @@ def sample_hops(g: ScoreGraph, n_targets: int, num_neighbors: Sequence[int], see
     out.extras["orig_id"] = order_arr
     assert n >= order_arr.size
     return out
+
+
+def merge_sampled(samples: Sequence[ScoreGraph]) -> ScoreGraph:
+    """Joint hop-ordered batch of neighbour-sampled subgraphs, the layout a NeighborLoader-style loader hands over for
+    a batch of seeds (reference datamodules/analysis.py:270-278 with transform_to_pyg; consumed at
+    models/analysis.py:948-961): nodes = [targets of all subgraphs | hop-1 nodes of all | hop-2 ...], per relation
+    edges = [hop-1 edges of all | hop-2 ...], `num_sampled_nodes/edges` = per-hop totals, `batch_size` = all targets.
+    Subgraphs stay disconnected (block structure), `batch` holds the subgraph id of every node."""
+    hops = len(samples[0].num_sampled_nodes["note"])
+    ets = samples[0].edge_types
+    # node id maps: subgraph-local (hop-ordered) -> global
+    maps = []
+    base = 0
+    hop_tot = [sum(s.num_sampled_nodes["note"][h] for s in samples) for h in range(hops)]
+    hop_base = np.concatenate([[0], np.cumsum(hop_tot)])
+    fill = [0] * hops
+    for s in samples:
+        m = np.empty(s.num_nodes["note"], dtype=np.int64)
+        lo = 0
+        for h in range(hops):
+            k = s.num_sampled_nodes["note"][h]
+            m[lo:lo + k] = hop_base[h] + fill[h] + np.arange(k)
+            fill[h] += k
+            lo += k
+        maps.append(m)
+    n_total = int(hop_base[-1])
+    batch = np.empty(n_total, dtype=np.int64)
+    on = np.empty(n_total, dtype=np.int64)
+    du = np.empty(n_total, dtype=np.int64)
+    for i, (s, m) in enumerate(zip(samples, maps)):
+        batch[m] = i
+        on[m] = s.onset_div
+        du[m] = s.duration_div
+    ei = {}
+    eph = {}
+    for et in ets:
+        parts = []
+        counts = []
+        for h in range(hops - 1):
+            c = 0
+            for s, m in zip(samples, maps):
+                lo = sum(s.num_sampled_edges[et][:h])
+                k = s.num_sampled_edges[et][h]
+                parts.append(m[s.edge_index[et][:, lo:lo + k]])
+                c += k
+            counts.append(c)
+        ei[et] = (np.concatenate(parts, axis=1) if parts else np.zeros((2, 0), dtype=np.int64)).astype(np.int64)
+        eph[et] = counts
+    return ScoreGraph(num_nodes={"note": n_total}, edge_index=ei, batch={"note": batch}, onset_div=on, duration_div=du,
+                      num_graphs=len(samples), num_sampled_nodes={"note": [int(v) for v in hop_tot]}, num_sampled_edges=eph,
+                      batch_size=int(hop_tot[0]))
+
+
+def make_sampled_batch(n_graphs: int, n_targets: int = 500, num_neighbors: Sequence[int] = (5, 5), first_seed: int = 0,
+                       score_notes: int = 800, first_target: int = 150, seeds: Optional[Sequence[int]] = None) -> ScoreGraph:
+    """`n_graphs` windows of `n_targets` target notes, each cut out of its own `score_notes`-note synthetic score and
+    neighbour-sampled with `num_neighbors` (the reference trains with subgraph_size 500 and [5] * (num_layers - 1):
+    train/train_analysisgnn.py:82,154), merged hop-ordered (`merge_sampled`)."""
+    seeds = list(seeds) if seeds is not None else [first_seed + i for i in range(n_graphs)]
+    return merge_sampled([sample_hops(make_score_graph(seed=sd, n_notes=score_notes), n_targets, num_neighbors,
+                                      seed=sd, first_target=first_target) for sd in seeds])
 
 
 def torch_inputs(g: ScoreGraph, in_channels: int = 25, device="cpu", seed: int = 0):

@@ -1,30 +1,35 @@
 #!/usr/bin/env python3
 """bench.py — subgraph-nodes/sec, forward+backward, HybridGNN L=3 H=256 (BASELINE.json).
 
-One "step" = one training pass of the hot path over one batch of synthetic input already
-resident in HBM: TorchAnalysisGNN(encoder=HybridGNN, L=3, H=256, out=128, 21 task heads,
-dropout 0.3, use_jk off — the analysisgnn-train CLI defaults, train/train_analysisgnn.py:52-70)
-forward, label-smoothed multi-task CE + feature loss, backward, gradient all-reduce (N>1),
-gradient clipping (1.0) and AdamW step.  The COO->CSR index is rebuilt every step (a fresh
-sampled batch arrives every step in the reference's loader).  Workload C2: 32 subgraphs x 500
-notes per GPU (weak scaling: per-GPU work fixed).
+One "step" = one training pass of the hot path over one batch of synthetic input already resident in
+HBM, as a training step of the reference runs it (analysisgnn-train CLI defaults, train/train_analysisgnn.py:
+52-97): TorchAnalysisGNN(encoder=HybridGNN, L=3, H=256, out=128, 21 task heads, dropout 0.3, use_jk off,
+logit_fusion off) forward on a neighbour-SAMPLED batch with the per-hop counts passed (models/analysis.py:
+960-961 — every layer is trimmed), the default objective (--mt_strategy wloss: learned task weights,
+models/chord.py:39-49, / number of tasks, + 0.1 * feature norm: models/analysis.py:1034-1036, :1072), backward,
+gradient all-reduce (N>1), gradient clipping (1.0) and AdamW.  The COO->CSR index is rebuilt every step (a
+fresh sampled batch arrives every step in the reference's loader).  Default workload "c2s": 32 sampled
+subgraphs (500 target notes + [5,5] hops each) per GPU (weak scaling: per-GPU work fixed).
 
-Launch:  python bench.py [--gpus N --steps K --warmup W]     (N>1 via torch.distributed.run)
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (hetero-SpMM
-aggregation kernel, HBM bound, live HIP-event timing) and `cpu_baseline` (oracle port on host cores).
+Launch:  python bench.py [--gpus N --steps K --warmup W]
+N > 1 without WORLD_SIZE in the environment: this process only spawns `python -m torch.distributed.run
+--nproc-per-node N bench.py ...` (before anything touches the GPU) and relays rank 0's JSON line and the exit
+code; under torch.distributed.run it is one rank.  Prints ONE JSON line on rank 0 with `roofline` (the
+workload's dominant hand-written aggregation kernel, HBM bound, live HIP-event timing) and `cpu_baseline`
+(oracle port on host cores).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402
 
 TASK_DICT = {  # train/train_analysisgnn.py:22-45 (duplicate key "organ_point" collapses, as in the reference)
     "cadence": 4, "localkey": 50, "tonkey": 50, "quality": 15, "inversion": 4, "root": 38, "bass": 38,
@@ -32,85 +37,173 @@ TASK_DICT = {  # train/train_analysisgnn.py:22-45 (duplicate key "organ_point" c
     "organ_point": 2, "tpc_in_label": 2, "tpc_is_root": 2, "tpc_is_bass": 2, "downbeat": 45, "note_degree": 49,
     "staff": 4,
 }
+C5_TASKS = {"cadence": 4, "localkey": 50, "romanNumeral": 185}
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
 N_SUB, N_NOTES, IN_CH, H, OUT, LAYERS = 32, 500, 25, 256, 128, 3
 
-
-def make_labels(n, device, seed):
-    g = torch.Generator().manual_seed(seed)
-    return {t: torch.randint(0, c, (n,), generator=g).to(device) for t, c in TASK_DICT.items()}
-
-
-def loss_fn(logits, labels, feat):
-    import torch.nn.functional as F
-    loss = 0.1 * feat.pow(2).mean()                                   # analysis.py:984, lambda_featl=0.1
-    for t, y in labels.items():
-        loss = loss + F.cross_entropy(logits[t], y, ignore_index=-1, label_smoothing=0.1)   # analysis.py:881-888
-    return loss
+WORKLOADS = {
+    "c2s": "C2 (sampled, the batch a training step sees): HybridGNN L=3 H=256 out=128, 21 task heads, 32 neighbour-sampled "
+           "subgraphs x (500 target notes + [5,5] hops) per GPU, per-hop counts passed (every layer trimmed)",
+    "c2": "C2 (whole graphs, no trimming): HybridGNN L=3 H=256 out=128, 21 task heads, 32 subgraphs x 500 notes per GPU",
+    "c3": "C3: HGT L=3 H=256 heads=4, note+beat+measure nodes, 6 relation types, 21 task heads, 32 subgraphs x 500 notes per GPU "
+          "(whole graphs)",
+    "c5": "C5: MetricalGNN L=4 H=512, heads cadence/localkey/romanNumeral, 32 subgraphs x 500 notes per GPU (whole graphs)",
+}
+METRICS = {"c2s": "subgraph-nodes/sec fwd+bwd, HybridGNN L=3 H=256", "c2": "subgraph-nodes/sec fwd+bwd, HybridGNN L=3 H=256",
+           "c3": "subgraph-nodes/sec fwd+bwd, HGT L=3 H=256", "c5": "subgraph-nodes/sec fwd+bwd, MetricalGNN L=4 H=512"}
 
 
-def spmm_alg_bytes(graph, n_rel_expected, H=H):
-    """B_alg = sum_r [4(N_dst+1) + 4 E_r] + 4H (N_src_unique + R N_dst), forward aggregation."""
-    ets = [et for et in graph.edge_index if et[2] == "note" and et[0] == "note"]
-    assert len(ets) == n_rel_expected
-    n = graph.num_nodes["note"]
-    idx = sum(4 * (n + 1) + 4 * graph.edge_index[et].shape[1] for et in ets)
-    return idx + 4 * H * (n + len(ets) * n), sum(graph.edge_index[et].shape[1] for et in ets)
-
-
-def cpu_baseline(n_sub=8, iters=5):
-    """Oracle port (oracle/encoders_ref.py, pure PyTorch CPU) of the same model on a bounded sample."""
-    from analysisgnn_amd.models import TorchAnalysisGNN
-    from analysisgnn_amd.synth import make_batch, torch_inputs
-    from oracle import encoders_ref as E, rnn_ref
-    rnn_ref.USE_FAST = True
-    g = make_batch(n_sub, N_NOTES)
-    torch.manual_seed(0)
-    m = TorchAnalysisGNN(g.metadata(), IN_CH, H, OUT, TASK_DICT, LAYERS, dropout=0.3, use_jk=False,
-                         encoder_type="hybridgnn")
-    P = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
-    I = torch_inputs(g, IN_CH, "cpu", 0)
-    labels = make_labels(I["batch_size"], "cpu", 1)
-    # the GPU box gives one-GPU jobs a 16-CPU share while torch sees every host core: oversubscribing made
-    # this oracle 6x slower, so pin the thread count to the share actually available
-    cores = max(1, min(16, len(os.sched_getaffinity(0)), os.cpu_count() or 1))
-    torch.set_num_threads(cores)
-
-    def step():
-        for p in P.values():
-            p.grad = None
-        x = E.analysis_encode(P, "hybridgnn", g.metadata(), LAYERS, I["pitch_spelling"], I["key_signature"],
-                              I["x_dict"], I["edge_index_dict"], I["batch_dict"], I["batch_size"])
-        loss = loss_fn(E.analysis_logits(P, x, list(TASK_DICT)), labels, x)
-        loss.backward()
-    step()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        step()
-    dt = (time.perf_counter() - t0) / iters
-    return {"value": I["batch_size"] / dt, "unit": "subgraph-nodes/s", "cores": cores, "kind": "port",
-            "sample": f"{n_sub} subgraphs x {N_NOTES} notes, fwd+bwd (no optimizer), eval-mode oracle, "
-                      f"{iters} iters after 1 warm-up, {dt*1e3:.1f} ms/iter"}
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"],
-                    help="c2 (default, the BASELINE metric): HybridGNN L=3 H=256; c3: HGT L=3 H=256 heads=4 with beat+measure "
-                         "nodes, 6 relation types; c5: MetricalGNN L=4 H=512, heads cadence/localkey/romanNumeral")
+    ap.add_argument("--workload", default="c2s", choices=list(WORKLOADS),
+                    help="c2s (default, the BASELINE metric on the batch a training step of the reference sees): " + WORKLOADS["c2s"] +
+                         "; c2: " + WORKLOADS["c2"] + "; c3: " + WORKLOADS["c3"] + "; c5: " + WORKLOADS["c5"])
+    ap.add_argument("--mt-strategy", default="wloss", choices=["wloss", "sum"],
+                    help="wloss (reference CLI default): learned uncertainty weights per task; sum: plain sum of the task losses")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-wgrad-overlap", action="store_true", help="A/B only: weight gradients on the main stream")
     ap.add_argument("--library-wgrad", action="store_true", help="A/B only: weight gradients through the library GEMM")
     ap.add_argument("--blas", default=None, choices=[None, "hipblaslt", "rocblas"], help="A/B only: torch's preferred BLAS library")
-    args = ap.parse_args()
+    ap.add_argument("--no-other", action="store_true", help="skip the secondary (whole-graph C2) measurement of the default run")
+    return ap.parse_args(argv)
 
-    from analysisgnn_amd import dp, graph, ops
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` as ONE command (the reference gets its ranks from one command too:
+    train/train_analysisgnn.py:138-146).  The parent never touches the GPU; it relays the children's output."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:                      # rank 0 prints the one JSON line; anything else goes to stderr
+        if ln.lstrip().startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return rc if rc != 0 else (0 if line is not None else 1)
+
+
+def make_labels(n, device, seed, tasks):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    return {t: torch.randint(0, c, (n,), generator=g).to(device) for t, c in tasks.items()}
+
+
+def build_workload(name: str, rank: int, world: int, n_sub: int = N_SUB):
+    """(graph, encoder_type, hidden, layers, tasks).  Rank r of G takes subgraphs {i : i mod G = r} of the global batch of
+    32 * G (dp.shard_units; DistributedSampler semantics): independent units, no data-path collective."""
+    from analysisgnn_amd.dp import shard_units
+    from analysisgnn_amd.synth import make_batch, make_sampled_batch
+    seeds = shard_units(n_sub * world, rank, world)
+    if name == "c2s":
+        g = make_sampled_batch(n_sub, N_NOTES, (5,) * (LAYERS - 1), seeds=seeds)      # train_analysisgnn.py:82,154
+        return g, "hybridgnn", H, LAYERS, TASK_DICT
+    if name == "c2":
+        return make_batch(n_sub, N_NOTES, seeds=seeds), "hybridgnn", H, LAYERS, TASK_DICT
+    if name == "c3":
+        g = make_batch(n_sub, N_NOTES, seeds=seeds, add_beats=True, add_measures=True)
+        keep = [et for et in g.edge_types if et[0] == "note"]       # 4 note-note + note->beat + note->measure
+        g.edge_index = {et: g.edge_index[et] for et in keep}
+        return g, "hgt", H, LAYERS, TASK_DICT
+    if name == "c5":
+        return make_batch(n_sub, N_NOTES, seeds=seeds), "metricalgnn", 512, 4, C5_TASKS
+    raise ValueError(name)
+
+
+def reference_objective(logits, labels, feat, params):
+    """The objective exactly as the reference composes it (models/analysis.py:1034-1036, :1072; models/chord.py:39-49),
+    on torch ops — the CPU baseline's loss."""
+    import torch
+    import torch.nn.functional as F
+    loss_sum = 0
+    for i, (t, y) in enumerate(labels.items()):
+        ce = F.cross_entropy(logits[t], y, ignore_index=-1, label_smoothing=0.1)
+        loss_sum = loss_sum + ((0.5 / (params[i] ** 2) * ce + torch.log(1 + params[i] ** 2)) if params is not None else ce)
+    return loss_sum / len(labels) + 0.1 * feat.pow(2).mean()
+
+
+def _percentiles(ts):
+    ts = sorted(ts)
+    k = len(ts)
+    return ts[k // 2], ts[max(0, int(0.1 * (k - 1)))], ts[min(k - 1, int(round(0.9 * (k - 1))))]
+
+
+def cpu_baseline(workload: str, mt_strategy: str):
+    """Oracle port (oracle/encoders_ref.py, pure PyTorch CPU: per relation index_select -> index_add_ -> divide -> Linear,
+    Python loops over relations and layers) of the same model on the same workload, fwd + objective + bwd.
+    BASELINE.md §3 protocol, bounded to ~30 s of CPU work: all cores of this job's CPU share on the full per-GPU batch
+    (32 subgraphs; 3 warm-up + 10 timed), and one thread on C1 (one subgraph; 2 + 8)."""
+    import torch
     from analysisgnn_amd.models import TorchAnalysisGNN
-    from analysisgnn_amd.synth import make_batch, torch_inputs
+    from analysisgnn_amd.synth import torch_inputs
+    from oracle import encoders_ref as E, rnn_ref
+    rnn_ref.USE_FAST = True
+
+    def run(n_sub, threads, warm, iters):
+        g, enc, hid, layers, tasks = build_workload(workload, 0, 1, n_sub)
+        torch.manual_seed(0)
+        m = TorchAnalysisGNN(g.metadata(), IN_CH, hid, OUT, tasks, layers, dropout=0.3, use_jk=False, logit_fusion=False,
+                             encoder_type=enc)
+        P = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+        params = torch.ones(len(tasks), requires_grad=True) if mt_strategy == "wloss" else None
+        I = torch_inputs(g, IN_CH, "cpu", 0)
+        labels = make_labels(I["batch_size"], "cpu", 1, tasks)
+        torch.set_num_threads(threads)
+
+        def step():
+            for p in P.values():
+                p.grad = None
+            x = E.analysis_encode(P, enc, g.metadata(), layers, I["pitch_spelling"], I["key_signature"], I["x_dict"],
+                                  I["edge_index_dict"], I["batch_dict"], I["batch_size"], I["neighbor_mask_node"],
+                                  I["neighbor_mask_edge"])
+            reference_objective(E.analysis_logits(P, x, list(tasks)), labels, x, params).backward()
+        for _ in range(warm):
+            step()
+        ts = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            step()
+            ts.append(time.perf_counter() - t0)
+        med, p10, p90 = _percentiles(ts)
+        return I["batch_size"] / med, med, p10, p90
+
+    # the GPU box gives one-GPU jobs a 16-CPU share while torch sees every host core: oversubscribing made this
+    # oracle 6x slower, so the thread count is the share actually available
+    cores = max(1, min(16, len(os.sched_getaffinity(0)), os.cpu_count() or 1))
+    v, med, p10, p90 = run(N_SUB, cores, 3, 10)
+    v1, med1, p101, p901 = run(1, 1, 2, 8)
+    return {"value": v, "unit": "subgraph-nodes/s", "cores": cores, "kind": "port",
+            "sample": f"workload {workload}: {N_SUB} subgraphs, fwd + objective ({mt_strategy}) + bwd (no optimizer), eval-mode oracle, "
+                      f"3 warm-up + 10 timed iters, median {med*1e3:.0f} ms/iter (p10 {p10*1e3:.0f}, p90 {p90*1e3:.0f}), {cores} threads "
+                      f"(host has {os.cpu_count()} CPUs; this job's share is {len(os.sched_getaffinity(0))})",
+            "single_thread": {"value": v1, "unit": "subgraph-nodes/s", "cores": 1,
+                              "sample": f"C1 shape (1 subgraph of workload {workload}), 2 warm-up + 8 timed iters, median {med1*1e3:.0f} ms/iter "
+                                        f"(p10 {p101*1e3:.0f}, p90 {p901*1e3:.0f})"}}
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    import torch
+    from analysisgnn_amd import dp, graph
+    from analysisgnn_amd.heads import MultiTaskLoss, training_loss
+    from analysisgnn_amd.models import TorchAnalysisGNN
+    from analysisgnn_amd.synth import torch_inputs
 
     if args.library_wgrad:
         from analysisgnn_amd import linear as _lin
@@ -124,44 +217,32 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    # rank r owns subgraphs {r*32 .. r*32+31}: independent units, no data-path collective
-    global TASK_DICT
-    enc, hid, layers = "hybridgnn", H, LAYERS
-    if args.workload == "c3":
-        g = make_batch(N_SUB, N_NOTES, first_seed=rank * N_SUB, add_beats=True, add_measures=True)
-        keep = [et for et in g.edge_types if et[0] == "note"]      # 4 note-note + note->beat + note->measure
-        g.edge_index = {et: g.edge_index[et] for et in keep}
-        enc = "hgt"
-    elif args.workload == "c5":
-        g = make_batch(N_SUB, N_NOTES, first_seed=rank * N_SUB)
-        enc, hid, layers = "metricalgnn", 512, 4
-        TASK_DICT = {"cadence": 4, "localkey": 50, "romanNumeral": 185}
-    else:
-        g = make_batch(N_SUB, N_NOTES, first_seed=rank * N_SUB)
+    g, enc, hid, layers, tasks = build_workload(args.workload, rank, world)
     I = torch_inputs(g, IN_CH, dev, seed=rank)
-    labels = make_labels(I["batch_size"], dev, 100 + rank)
+    labels = make_labels(I["batch_size"], dev, 100 + rank, tasks)
     torch.manual_seed(0)                                            # identical replicas
-    model = TorchAnalysisGNN(g.metadata(), IN_CH, hid, OUT, TASK_DICT, layers, dropout=0.3, use_jk=False,
+    model = TorchAnalysisGNN(g.metadata(), IN_CH, hid, OUT, tasks, layers, dropout=0.3, use_jk=False, logit_fusion=False,
                              encoder_type=enc).to(dev).train()
+    clf_loss = MultiTaskLoss(list(tasks), requires_grad=(args.mt_strategy == "wloss")).to(dev)     # analysis.py:899-908
+    trainable = torch.nn.ModuleDict({"model": model, "clf_loss": clf_loss})
     # parameters consumed concatenated (task-head layers, GRU direction pairs) sit back to back: their cats are views
-    params, tight = dp.plan_parameters(model)
+    params, tight = dp.plan_parameters(trainable)
     flat = dp.FlatGradBuffer(params, views=False, tight=tight)
     # the GRU layers' weight-gradient work on its own stream, joined in flat.pack() — only where the sequence branch is
     # the longer one (C2; with HGT / MetricalGNN the graph branch is, and the extra stream only adds contention)
-    dp.enable_wgrad_overlap(not args.no_wgrad_overlap and args.workload == "c2", "sequence")
+    dp.enable_wgrad_overlap(not args.no_wgrad_overlap and args.workload in ("c2", "c2s"), "sequence")
     opt = dp.FlatAdamW(params, flat, lr=5e-3, weight_decay=5e-3)     # analysis.py:1380-1381 hyper-parameters
     graph.index_cache_enabled = False                               # fresh batch every step: rebuild the CSR
 
-    from analysisgnn_amd.heads import training_loss
-    label_mat = torch.stack([labels[t] for t in TASK_DICT])             # [T, N]
+    label_mat = torch.stack([labels[t] for t in tasks])             # [T, N]
     one = torch.ones((), dtype=torch.float32, device=dev)
 
     def fwd_bwd():
         flat.zero()
         x = model.encode(I["pitch_spelling"], I["key_signature"], I["x_dict"], I["edge_index_dict"], I["batch_dict"],
-                         I["batch_size"], None, None)
+                         I["batch_size"], I["neighbor_mask_node"], I["neighbor_mask_edge"])      # analysis.py:953-961
         logits, offs, _ = model.forward_clf_fused(x)
-        loss, _ = training_loss(logits, offs, label_mat, x, 0.1, 0.1, -1)      # sum_t CE_t + 0.1 * x.pow(2).mean(), analysis.py:1072
+        loss, _ = training_loss(logits, offs, label_mat, x, 0.1, 0.1, -1, task_params=clf_loss.weights())   # analysis.py:1034-1036, :1072
         loss.backward(gradient=one)                                # a resident 1.0: no fill launch for the root gradient
         flat.pack()
         return loss
@@ -169,7 +250,7 @@ def main():
     def update():
         opt.step(max_norm=1.0)                                      # clip + AdamW: agnn_adamw_f32 (two launches)
 
-    # The whole step is ~450 launches; issued one by one from Python they cost more host time than GPU time, so
+    # The whole step is a few hundred launches; issued one by one from Python they cost more host time than GPU time, so
     # the two launch sequences (forward+backward+gradient gather; clip+AdamW) are captured ONCE into hipGraphs and
     # replayed, with the gradient all-reduce between them.  The batch tensors are static buffers that a loader would
     # refill; the graphs still rebuild the CSR from the COO edge lists on every replay.
@@ -216,72 +297,113 @@ def main():
     dt = time.perf_counter() - t0
     dt = dp.max_over_ranks(dt)
     assert torch.isfinite(loss).item(), "loss diverged"
-    # Live timing of the dominant aggregation kernel.  Inside the timed region the launches are replayed from a
-    # hipGraph, where single kernels cannot be bracketed by events; and an event pair around ONE eager launch mostly
-    # measures the ~8 us of event / dispatch overhead.  So the same launch (this step's forward hetero-SpMM: same CSR,
-    # same shapes) is captured REP times back to back into a small graph and HIP events bracket each replay on the
-    # launch stream: average launch duration = replay time / REP (kernel + the ~1.5 us kernel-to-kernel boundary).
+
+    roof = roofline(args.workload, g, I, hid, layers, dev) if rank == 0 else None
+    if rank == 0:
+        nodes = I["batch_size"] * world * args.steps
+        e_tot = sum(int(e.shape[1]) for e in g.edge_index.values())
+        out = {
+            "metric": METRICS[args.workload], "value": nodes / dt, "unit": "subgraph-nodes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": WORKLOADS[args.workload] + f"; {g.num_nodes['note']} notes, {e_tot} edges per GPU; train step = fwd + "
+                                   f"objective ({args.mt_strategy}) + bwd + allreduce + clip + AdamW, CSR rebuilt every step; "
+                                   + ("hipGraph replay" if graphs is not None else "eager launches"),
+                       "workload_id": args.workload, "per_gpu_subgraphs": N_SUB, "target_notes_per_subgraph": N_NOTES,
+                       "objective": args.mt_strategy, "sharding": "rank r takes subgraphs {i : i mod G = r}",
+                       "parallelism": f"dp{world}"},
+            "roofline": roof,
+        }
+        if world == 1 and args.workload == "c2s" and not args.no_other:
+            # continuity with round 1's line (whole graphs, nothing trimmed): a child process, same steps
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "c2", "--no-cpu-baseline", "--steps",
+                                    str(args.steps), "--warmup", str(args.warmup), "--mt-strategy", args.mt_strategy],
+                                   capture_output=True, text=True, timeout=300)
+                o = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                out["other_workloads"] = {"c2": {"value": o["value"], "ms_per_step": o["ms_per_step"], "workload": o["config"]["workload"],
+                                                 "roofline": o["roofline"]}}
+            except Exception as e:                              # secondary figure only
+                out["other_workloads"] = {"c2": f"not measured ({type(e).__name__})"}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.mt_strategy)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def roofline(workload, g, I, hid, layers, dev):
+    """Live timing of the workload's dominant hand-written aggregation kernel.  Inside the timed region the launches are
+    replayed from a hipGraph, where single kernels cannot be bracketed by events; and an event pair around ONE eager launch
+    mostly measures the ~8 us of event / dispatch overhead.  So the same launch (same CSR, same shapes as in the step) is
+    captured REP times back to back into a small graph and HIP events bracket each replay on the launch stream: average
+    launch duration = replay time / REP (kernel + the ~1.5 us kernel-to-kernel boundary).
+    ALGORITHMIC bytes: B_alg = sum_r [4 (N_dst + 1) + 4 E_r] + 4 H (N_src_unique + R N_dst) per launch."""
+    import numpy as np
+    import torch
+    from analysisgnn_amd import ops
+    from analysisgnn_amd.encoders import TrimPlan
     from analysisgnn_amd.graph import HeteroIndex
-    hix = HeteroIndex(I["edge_index_dict"], {k: int(v.shape[0]) for k, v in I["x_dict"].items()})
-    ets4 = [et for et in hix.edge_types if et[0] == "note" and et[2] == "note"]
-    spec4 = ops.AggSpec(fwd=[hix.fwd[e] for e in ets4], bwd=[hix.bwd[e] for e in ets4], src_id=[0] * len(ets4),
-                        n_rows=I["batch_size"], mean=True, shared_slot=False)
-    xs = torch.randn(I["batch_size"], hid, device=dev)
     REP = 10
 
-    def timed(fn, use_graph=True):
+    def timed(fn):
         fn(); torch.cuda.synchronize(dev)
         run, per = fn, 1
-        if use_graph:
-            try:
-                sgraph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(sgraph):
-                    for _ in range(REP):
-                        fn()
-                run, per = sgraph.replay, REP
-            except Exception:
-                run, per = fn, 1
+        try:
+            sgraph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(sgraph):
+                for _ in range(REP):
+                    fn()
+            run, per = sgraph.replay, REP
+        except Exception:
+            run, per = fn, 1
         ts = []
         for _ in range(12):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); run(); e1.record(); e1.synchronize()
             ts.append(e0.elapsed_time(e1) * 1e-3 / per)
-        return ts[2:]
+        ts = ts[2:]
+        return sum(ts) / len(ts), len(ts) * per
 
+    if workload == "c3":
+        from analysisgnn_amd.hgt import attention_roofline_case
+        return attention_roofline_case(g, I, hid, dev, timed, HBM_PEAK)
+
+    n_nodes = {k: int(v.shape[0]) for k, v in I["x_dict"].items()}
+    hix = HeteroIndex(I["edge_index_dict"], n_nodes)
+    ets = [et for et in hix.edge_types if et[0] == "note" and et[2] == "note"]
+    plan = TrimPlan(layers, I["x_dict"], I["edge_index_dict"], I["neighbor_mask_node"], I["neighbor_mask_edge"])
+    layer = 1 if workload == "c2s" else 0                  # c2s: the first TRIMMED layer (rowend path), otherwise layer 0
+    hix.prepare_trim(plan.e_keep)
+    n_dst = plan.n_keep[layer]["note"]
+    e_keep = [plan.e_keep[layer][et] for et in ets]
+    spec = ops.AggSpec(fwd=[hix.fwd[e] for e in ets], bwd=[hix.bwd[e] for e in ets], src_id=[0] * len(ets), n_rows=n_dst, mean=True,
+                       shared_slot=False, e_limit=e_keep if any(k is not None for k in e_keep) else None)
+    n_src = plan.n_keep[layer - 1]["note"] if layer > 0 else n_nodes["note"]
+    xs = torch.randn(n_src, hid, device=dev)
     with torch.no_grad():
-        fwd = timed(lambda: ops.aggregate(spec4, [xs]))
-    trace = None
-    if rank == 0:
-        nodes = I["batch_size"] * world * args.steps
-        # live timing of the dominant aggregation kernel: forward hetero SpMM, 4 relations -> [N, 4H]
-        b_alg, e_tot = spmm_alg_bytes(g, 4, hid)
-        t_fwd = sum(fwd) / max(len(fwd), 1)
-        out = {
-            "metric": {"c2": "subgraph-nodes/sec fwd+bwd, HybridGNN L=3 H=256", "c3": "subgraph-nodes/sec fwd+bwd, HGT L=3 H=256",
-                       "c5": "subgraph-nodes/sec fwd+bwd, MetricalGNN L=4 H=512"}[args.workload], "value": nodes / dt,
-            "unit": "subgraph-nodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": {"c3": "C3: HGT L=3 H=256 heads=4, note+beat+measure, 6 relation types; otherwise as C2 — ",
-                                    "c5": "C5: MetricalGNN L=4 H=512, heads cadence/localkey/romanNumeral; otherwise as C2 — ",
-                                    "c2": ""}[args.workload] +
-                                   "C2: HybridGNN L=3 H=256 out=128, 21 task heads, 32 subgraphs x 500 notes per GPU "
-                                   "(4 note-note relations, %d edges), train step fwd+loss+bwd+allreduce+clip+AdamW, "
-                                   "CSR rebuilt every step; " % e_tot + ("hipGraph replay" if graphs is not None else "eager launches"), "per_gpu_subgraphs": N_SUB, "notes_per_subgraph": N_NOTES,
-                       "parallelism": f"dp{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k_spmm_fast6<1,1,false,false,false> forward hetero-SpMM (R=4, N=16000, H=256 -> [N,4H])",
-                         "achieved": b_alg / t_fwd / 1e9 if t_fwd > 0 else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": (b_alg / t_fwd) / HBM_PEAK if t_fwd > 0 else None,
-                         # HBM bytes per launch from rocprofv3 PMC passes of this kernel at this shape (FETCH_SIZE x2 gfx950
-                         # correction + WRITE_SIZE, separate passes): profiles/r01_spmm_kernel_study.md part 2 — not re-collected per run
-                         "traffic": 83.2e6 if args.workload == "c2" else None,
-                         "alg_bytes_per_launch": b_alg, "avg_us": t_fwd * 1e6, "launches": len(fwd) * REP, "timing": "HIP events around hipGraph replays of 10 back-to-back launches"},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+        t_k, launches = timed(lambda: ops.aggregate(spec, [xs]))
+    # algorithmic bytes of exactly this launch
+    idx_bytes, e_kept, srcs = 0, 0, []
+    for et, k in zip(ets, e_keep):
+        ei = g.edge_index[et][:, :k] if k is not None else g.edge_index[et]
+        ei = ei[:, ei[1] < n_dst]
+        idx_bytes += 4 * (n_dst + 1) + 4 * ei.shape[1]
+        e_kept += int(ei.shape[1])
+        srcs.append(ei[0])
+    n_src_unique = int(np.unique(np.concatenate(srcs)).size)
+    b_alg = idx_bytes + 4 * hid * (n_src_unique + len(ets) * n_dst)
+    trimmed = any(k is not None for k in e_keep)
+    ch = hid // 256
+    return {"bound": "hbm",
+            "kernel": f"k_spmm_fast7<{ch},false,false,false,false> forward hetero-SpMM, layer {layer} of the step "
+                      f"({'trimmed: row ends from rowend' if trimmed else 'untrimmed'}; R={len(ets)}, N_dst={n_dst}, E={e_kept}, H={hid} -> [N,{len(ets)}H])",
+            "achieved": b_alg / t_k / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": (b_alg / t_k) / HBM_PEAK,
+            # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), not
+            # from this run: see the file named below; null here rather than a constant
+            "traffic": None, "traffic_source": "profiles/r02_spmm_pmc.md (rocprofv3 --pmc passes of this launch)",
+            "alg_bytes_per_launch": b_alg, "n_src_unique": n_src_unique, "avg_us": t_k * 1e6, "launches": launches,
+            "timing": "HIP events around hipGraph replays of 10 back-to-back launches"}
 
 
 if __name__ == "__main__":

@@ -97,6 +97,19 @@ int agnn_csr_build(int n_seg, const agnn_coo_seg_t* segs /* (host) */,
 int agnn_csr_rowend(const int32_t* rowptr, const int32_t* perm, int64_t n_rows, int64_t e_limit,
                     int32_t* rowend, agnn_stream_t stream);
 
+/* The same for up to AGNN_ROWEND_MAX_ITEMS (CSR, limit) pairs in ONE launch: a sampled batch needs the row ends of
+ * every relation, in both directions, for every trimmed layer (reference models/cadence.py:165-173 trims per layer;
+ * R = 4, L = 3: 16 items). */
+#define AGNN_ROWEND_MAX_ITEMS 64
+typedef struct {
+  const int32_t* rowptr;   /* (device) [n_rows + 1] */
+  const int32_t* perm;     /* (device) shared with rowptr's offsets */
+  int32_t* rowend;         /* (device) [n_rows] out */
+  int32_t n_rows;
+  int32_t e_limit;
+} agnn_rowend_item_t;
+int agnn_csr_rowend_batch(int n_items, const agnn_rowend_item_t* items /* (host) */, agnn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Multi-relation segmented gather-reduce ("hetero SpMM").  For every output row i < n_rows and
  * relation r < n_rel:
@@ -344,21 +357,28 @@ int agnn_multitask_ce_scale_f32(const float* dlogits, int64_t ld, const int32_t*
 
 /* ------------------------------------------------------------------------------------------
  * Training loss of one step in two launches, its gradient in one:
- *     total = sum_t loss[t] + lambda_feat * mean(feat^2)
- * i.e. the per-task label-smoothed cross entropies above plus the reference's feature-norm term
- * (ref: models/analysis.py:984 `feature_loss = x.pow(2).mean()`, :1072 `... + feature_loss * self.lambda_featl`, :910
- * default 0.1).  Same per-task outputs as agnn_multitask_ce_f32, plus `total` (device scalar).  feat [n_rows, feat_cols]
- * (ld_feat) may be NULL (no feature term).  `workspace` (agnn_train_loss_workspace_bytes(), 256-byte aligned) must be
- * ZERO-FILLED before its first use; every call leaves it zero-filled again (it holds the ticket of the fixed-order final
- * sum).  Backward, given g = d(objective)/d(total) as a DEVICE scalar:
+ *     total = ce_scale * sum_t (w_t * loss[t] + reg_t) + lambda_feat * mean(feat^2)
+ *     task_param == NULL: w_t = 1, reg_t = 0;  else p = task_param[t]: w_t = 0.5 / p^2, reg_t = log(1 + p^2)
+ * i.e. the per-task label-smoothed cross entropies above, combined as the reference's MultiTaskLoss does (learned
+ * uncertainty weights, ref models/chord.py:39-49; selected by the CLI default --mt_strategy wloss, models/analysis.py:
+ * 899-908), divided by the number of tasks (ce_scale = 1/T: models/analysis.py:1036), plus the feature-norm term
+ * (models/analysis.py:984 `feature_loss = x.pow(2).mean()`, :1072 `... + feature_loss * self.lambda_featl`, :910 default
+ * 0.1).  Same per-task outputs as agnn_multitask_ce_f32, plus `total` (device scalar), `wscale[t]` = ce_scale * w_t *
+ * inv_count[t] (the per-task gradient scale: hand it to agnn_train_loss_bwd_f32 as its `inv_count`) and `dparam[t]` =
+ * d total / d p_t = ce_scale * (2 p / (1 + p^2) - loss[t] / p^3) (0 without task_param); wscale / dparam may be NULL.
+ * A task without any valid row contributes loss 0 (torch: NaN).  feat [n_rows, feat_cols] (ld_feat) may be NULL (no
+ * feature term).  `workspace` (agnn_train_loss_workspace_bytes(), 256-byte aligned) must be ZERO-FILLED before its first
+ * use; every call leaves its ticket zero again (it orders the fixed-order final sum).  Backward, given g =
+ * d(objective)/d(total) as a DEVICE scalar:
  *     out[n, c]   = dlogits[n, c] * g * inv_count[task(c)]          (columns outside the segments: 0)
  *     dfeat[n, c] = g * 2 * lambda_feat / (n_rows * feat_cols) * feat[n, c]        (dfeat NULL to skip)
  * ------------------------------------------------------------------------------------------ */
 size_t agnn_train_loss_workspace_bytes(void);
 int agnn_train_loss_f32(const float* logits, int64_t ld, const int32_t* seg_off, int32_t n_tasks, const int64_t* labels,
                         int64_t n_rows, float label_smoothing, int64_t ignore_index, const float* feat, int64_t ld_feat,
-                        int32_t feat_cols, float lambda_feat, float* row_loss, float* dlogits, float* loss,
-                        float* inv_count, float* total, void* workspace, size_t workspace_bytes, agnn_stream_t stream);
+                        int32_t feat_cols, float lambda_feat, const float* task_param, float ce_scale, float* row_loss,
+                        float* dlogits, float* loss, float* inv_count, float* total, float* wscale, float* dparam,
+                        void* workspace, size_t workspace_bytes, agnn_stream_t stream);
 int agnn_train_loss_bwd_f32(const float* dlogits, int64_t ld, const int32_t* seg_off, int32_t n_tasks, int64_t n_rows,
                             int32_t n_cols, const float* inv_count, const float* g, float* out, int64_t ld_out,
                             const float* feat, int64_t ld_feat, int32_t feat_cols, float lambda_feat, float* dfeat,

@@ -100,15 +100,19 @@ def test_grouped_projection_matches_per_task_linear(K, classes, N):
     assert_close(bg.grad, b64.grad.float(), 1e-5, "db")
 
 
+@pytest.mark.parametrize("wloss", [False, True])
 @pytest.mark.parametrize("extra", [(), (5,), (3,)])      # 335 logit columns (scalar rows) / 340 (float4 backward) / 338 (float2)
 @pytest.mark.parametrize("N,lam,gscale", [(301, 0.1, 1.0), (16000, 0.1, 1.0), (37, 0.5, 3.0)])
-def test_training_loss_matches_torch(N, lam, gscale, extra):
-    """heads.training_loss (agnn_train_loss_f32 / _bwd_f32) = sum_t CE_t + lam * feat.pow(2).mean() (analysis.py:881-888, :984,
-    :1072) against F.cross_entropy on the CPU; tolerance 1e-4 relative (fp32 sums in a different order).  Called twice:
-    the ticket workspace must be left clean, and the result must be bitwise reproducible."""
+def test_training_loss_matches_torch(N, lam, gscale, extra, wloss):
+    """heads.training_loss (agnn_train_loss_f32 / _bwd_f32) against the objective built exactly as the reference builds it
+    (models/analysis.py:1034-1036: MultiTaskLoss total / number of tasks; :984, :1072: + lambda * feat.pow(2).mean();
+    models/chord.py:39-49: 0.5 / p_i^2 * CE_i + log(1 + p_i^2) when the weights are learned) with F.cross_entropy on the
+    CPU; tolerance 1e-4 relative (fp32 sums in a different order).  Called twice: the ticket workspace must be left
+    clean, and the result must be bitwise reproducible."""
     from analysisgnn_amd.heads import training_loss
     g = torch.Generator().manual_seed(N)
     C = list(TASKS.values()) + list(extra)
+    T = len(C)
     offs = [0]
     for c in C:
         offs.append(offs[-1] + c)
@@ -116,22 +120,63 @@ def test_training_loss_matches_torch(N, lam, gscale, extra):
     feat = torch.randn(N, 128, generator=g)
     labels = torch.stack([torch.randint(0, c, (N,), generator=g) for c in C])
     labels[1, ::5] = -1
-    labels[3, :] = -1                                    # a task with no valid row
+    labels[3, :] = -1                                    # a task with no valid row (0 here; torch gives NaN: documented)
+    params = (0.5 + torch.rand(T, generator=g) * 1.5) if wloss else None
     lr, fr = logits.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    pr = params.clone().requires_grad_(True) if wloss else None
     per = torch.stack([torch.nan_to_num(F.cross_entropy(lr[:, offs[i]:offs[i + 1]], labels[i], ignore_index=-1, label_smoothing=0.1), nan=0.0)
-                       for i in range(len(C))])
-    ref = per.sum() + lam * fr.pow(2).mean()
+                       for i in range(T)])
+    loss_sum = 0
+    for i in range(T):                                   # models/chord.py:41-46
+        loss_sum = loss_sum + ((0.5 / (pr[i] ** 2) * per[i] + torch.log(1 + pr[i] ** 2)) if wloss else per[i])
+    ref = loss_sum / T + lam * fr.pow(2).mean()
     (ref * gscale).backward()
     lg, fg = logits.to(DEV).requires_grad_(True), feat.to(DEV).requires_grad_(True)
+    pg = params.to(DEV).requires_grad_(True) if wloss else None
     outs = []
     for _ in range(2):
         lg.grad = fg.grad = None
-        total, per_task = training_loss(lg, offs, labels.to(DEV), fg, lam, 0.1, -1)
+        if wloss:
+            pg.grad = None
+        total, per_task = training_loss(lg, offs, labels.to(DEV), fg, lam, 0.1, -1, task_params=pg)
         (total * gscale).backward()
-        outs.append((total.detach().clone(), lg.grad.clone(), fg.grad.clone()))
+        outs.append((total.detach().clone(), lg.grad.clone(), fg.grad.clone()) + ((pg.grad.clone(),) if wloss else ()))
     assert_close(outs[0][0], ref.detach(), 1e-4, "total")
     assert_close(per_task, per.detach(), 1e-4, "per-task losses")
     assert_close(outs[0][1], lr.grad, 1e-4, "dlogits")
     assert_close(outs[0][2], fr.grad, 1e-4, "dfeat")
+    if wloss:
+        assert_close(outs[0][3], pr.grad, 1e-4, "dparams")
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+def test_training_loss_label_checks():
+    """Labels of the wrong dtype / shape are refused on the host; a label outside [0, C) that is not ignore_index makes the
+    loss NaN instead of being read out of range (torch: device assert)."""
+    from analysisgnn_amd import _lib
+    from analysisgnn_amd.heads import training_loss, MultiTaskLoss
+    offs = [0, 4, 10]
+    logits = torch.randn(33, 10, device=DEV)
+    feat = torch.randn(33, 8, device=DEV)
+    labels = torch.zeros(2, 33, dtype=torch.long, device=DEV)
+    with pytest.raises(_lib.AgnnError):
+        training_loss(logits, offs, labels.int(), feat)
+    with pytest.raises(_lib.AgnnError):
+        training_loss(logits, offs, labels.t().contiguous(), feat)
+    total, _ = training_loss(logits, offs, labels, feat)
+    assert torch.isfinite(total)
+    bad = labels.clone()
+    bad[0, 5] = 4                                          # task 0 has 4 classes
+    total, _ = training_loss(logits, offs, bad, feat)
+    assert torch.isnan(total)
+    bad[0, 5] = -100
+    assert torch.isnan(training_loss(logits, offs, bad, feat)[0])
+    # the module form (dict in, dict out: models/chord.py:39-49) agrees with the fused objective
+    m = MultiTaskLoss(["a", "b"]).to(DEV)
+    with torch.no_grad():
+        m.params.copy_(torch.tensor([0.7, 1.3]))
+    out = m({"a": logits[:, :4], "b": logits[:, 4:]}, {"a": labels[0], "b": labels[1]})
+    total, per = training_loss(logits, offs, labels, feat, 0.0, task_params=m.params, ce_scale=1.0)
+    assert_close(out["total"].detach(), total.detach(), 1e-5, "module total")
+    assert_close(torch.stack([out["a"], out["b"]]).detach(), per, 1e-6, "module per-task")

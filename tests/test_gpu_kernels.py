@@ -151,7 +151,8 @@ def test_spmm_filters_and_trim():
 
 
 def test_fast_and_generic_kernels_agree():
-    """Same launch through the specialised fast path and through the generic kernel (flag AGNN_SPMM_GENERIC)."""
+    """Same launch through the specialised fast path and through the generic kernel (flag AGNN_SPMM_GENERIC); both are
+    compared with the C oracle inside _spmm_case."""
     from analysisgnn_amd import ops
     for H in (256, 512):
         for kw in (dict(mean=True, shared=False, with_self=False), dict(mean=True, shared=False, with_self=True),
@@ -163,6 +164,34 @@ def test_fast_and_generic_kernels_agree():
                 _spmm_case(300, 300, [1500, 2, 700, 0, 90], H, seed=H, **kw)
             finally:
                 ops.SPMM_VARIANT = 0
+
+
+@pytest.mark.parametrize("H", [256, 512])
+@pytest.mark.parametrize("variant", [0, 1024])
+def test_fast_path_trimmed_and_filtered(H, variant):
+    """What a training step of the reference launches (models/analysis.py:960-961 always passes the per-hop counts, so
+    every layer is trimmed): row ends from `rowend` (forward), `rowend` + column limit + 1/deg column scales (backward),
+    and the onset pooling's predicates (models/analysis.py:581-584) — through the fast kernel (k_spmm_fast7, FILT and
+    plain) and through the generic one, each against the C oracle."""
+    from analysisgnn_amd import ops
+    ops.SPMM_VARIANT = variant
+    try:
+        # forward of a trimmed SAGE layer: per-relation COO prefixes, one relation untrimmed, one trimmed to nothing
+        _spmm_case(300, 300, [1500, 40, 700, 0, 90], H, mean=True, shared=False, with_self=False,
+                   trim=[900, 40, 1, 0, 0], seed=H + 1)
+        # its backward: relations summed into one slot, 1/deg scales, trimmed rows and the column limit
+        _spmm_case(300, 300, [1500, 40, 700, 0, 90], H, mean=False, shared=True, with_self=False, colscale=True,
+                   trim=[900, 40, 1, 0, 0], col_limit=211, seed=H + 2)
+        # onset pooling forward (self numerator, self loops skipped, column limit) and backward
+        _spmm_case(300, 300, [1400], H, mean=True, shared=True, with_self=True, skip_self=True, col_limit=170, seed=H + 3)
+        _spmm_case(300, 300, [1400], H, mean=False, shared=True, with_self=False, skip_self=True, col_limit=170,
+                   colscale=True, seed=H + 4)
+        # rows with more than 64 neighbours (ids beyond the registers: scalar-load loop) with both predicates and a trim
+        _spmm_case(40, 60, [3000, 70], H, mean=True, shared=False, with_self=True, skip_self=True, col_limit=41,
+                   trim=[2500, 70], seed=H + 5)
+        _spmm_case(40, 500, [3000], H, mean=True, shared=False, with_self=False, trim=[2999], seed=H + 6)
+    finally:
+        ops.SPMM_VARIANT = 0
 
 
 def test_spmm_c2_shape_against_oracle():
