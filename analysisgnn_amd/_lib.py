@@ -9,7 +9,8 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libagnn_hip.so")
+# AGNN_LIB: another build of the same C-ABI (scripts/csr_memset_probe.py loads the memset-probe variant); normally unset
+LIB_PATH = os.environ.get("AGNN_LIB") or os.path.join(_HERE, "libagnn_hip.so")
 MAX_SEG = 32
 
 SPMM_MEAN, SPMM_SKIP_SELF, SPMM_ACCUM = 1, 2, 4
@@ -66,7 +67,8 @@ SIGNATURES = {
     "agnn_version": (C.c_int, []),
     "agnn_csr_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "agnn_csr_build": (C.c_int, [C.c_int, C.POINTER(CooSeg), C.c_void_p, C.c_void_p, C.c_void_p,
-                                 C.c_void_p, C.c_size_t, C.c_void_p]),
+                                 C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "agnn_check_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "agnn_csr_rowend": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "agnn_csr_rowend_batch": (C.c_int, [C.c_int, C.POINTER(RowendItem), C.c_void_p]),
     "agnn_spmm_f32": (C.c_int, [C.c_int, C.POINTER(Rel), C.c_int64, C.c_int32, C.c_void_p, C.c_int64,
@@ -89,7 +91,8 @@ SIGNATURES = {
     "agnn_gated_bwd_src_f32": (C.c_int, [C.POINTER(Gated), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "agnn_norm_act_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "agnn_norm_act_fwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float,
-                                        C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                        C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
     "agnn_norm_act_bwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float,
                                         C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -168,6 +171,26 @@ def require_gpu(*tensors: Optional[torch.Tensor]) -> torch.device:
     if dev is None:
         raise AgnnError("no tensor given")
     return dev
+
+
+_STATUS: dict = {}
+
+
+def status_word(device: torch.device) -> torch.Tensor:
+    """The device-side status word handed to kernels that can detect an inconsistent index (agnn_csr_build): int32[1],
+    zero-initialised once per device, only ever incremented."""
+    key = str(device)
+    if key not in _STATUS:
+        if torch.cuda.is_current_stream_capturing():
+            raise AgnnError("the device status word must exist before a hipGraph capture starts (it would be re-zeroed by every "
+                            "replay): run the step once eagerly first, or call _lib.status_word(device)")
+        _STATUS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _STATUS[key]
+
+
+def check_device_status(device: torch.device) -> None:
+    """Synchronises and raises AgnnError when a kernel flagged an inconsistency since the word was created."""
+    check(load().agnn_check_status(status_word(device).data_ptr(), stream_ptr(device)), "agnn_check_status")
 
 
 def stream_ptr(device: torch.device) -> int:

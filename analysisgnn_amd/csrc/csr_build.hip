@@ -69,17 +69,25 @@ __global__ void k_rowstart_zero(int32_t total_rows, int32_t* __restrict__ rowsta
 }
 
 // vals[rowstart[key] + slot] = edge id; the counters return to zero
+// With clean counters every position is inside the row (slot < count, rowstart from the scan of the same counts).  A
+// position outside the edge array means the counters were NOT what k_count left (round 1: a memset node that had not
+// zeroed them before k_count ran): nothing is written out of range, and the caller's status word is bumped so that the
+// build is reported as failed (agnn_check_status) instead of passing on an index with missing edges.
 __global__ void k_scatter(const uint32_t* __restrict__ keys, int32_t e_total, uint32_t sentinel,
                           const int32_t* __restrict__ rowstart, uint32_t* __restrict__ cnt, uint32_t* __restrict__ vals,
-                          uint32_t* __restrict__ rowof) {
+                          uint32_t* __restrict__ rowof, int32_t* __restrict__ status) {
   for (int32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < e_total; e += gridDim.x * blockDim.x) {
     const uint32_t key = keys[e];
     if (key >= sentinel) continue;
-    const uint32_t slot = atomicSub(cnt + key, 1u) - 1u;
+    const uint32_t before = atomicSub(cnt + key, 1u);
+    const uint32_t slot = before - 1u;
     const uint32_t pos = static_cast<uint32_t>(rowstart[key]) + slot;
-    if (pos < static_cast<uint32_t>(e_total)) {                 // always true with clean counters; never write outside
+    const bool inside = before != 0u && pos < static_cast<uint32_t>(e_total) && pos < static_cast<uint32_t>(rowstart[key + 1]);
+    if (inside) {
       vals[pos] = static_cast<uint32_t>(e);
       rowof[pos] = key;
+    } else if (status != nullptr) {
+      atomicAdd(status, 1);
     }
   }
 }
@@ -247,7 +255,7 @@ extern "C" size_t agnn_csr_workspace_bytes(int64_t e_total, int64_t total_rows) 
 }
 
 extern "C" int agnn_csr_build(int n_seg, const agnn_coo_seg_t* segs, int32_t* rowstart, int32_t* col,
-                              int32_t* perm, void* workspace, size_t workspace_bytes,
+                              int32_t* perm, void* workspace, size_t workspace_bytes, int32_t* status,
                               agnn_stream_t stream_) {
   using namespace agnn;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -292,11 +300,18 @@ extern "C" int agnn_csr_build(int n_seg, const agnn_coo_seg_t* segs, int32_t* ro
   void* temp = ws + l.temp;
   size_t temp_bytes = l.temp_bytes;
 
+  hipError_t e = hipSuccess;
+#ifdef AGNN_CSR_MEMSET_PROBE
+  // scripts/csr_memset_probe.py only (libagnn_hip_memsetprobe.so): round 1's way of clearing the counters, kept to check
+  // with the status word whether a memset node leaves them stale under graph replay.  Never in libagnn_hip.so.
+  e = hipMemsetAsync(cnt, 0, static_cast<size_t>(r_total + 2) * sizeof(uint32_t), stream);
+  if (e != hipSuccess) return fail(AGNN_ERUNTIME, "csr_build/memset: %s", hipGetErrorString(e));
+#else
   int blocks_z = static_cast<int>((r_total + 2 + threads - 1) / threads);
   if (blocks_z > 2048) blocks_z = 2048;
   hipLaunchKernelGGL(k_zero_u32, dim3(blocks_z), dim3(threads), 0, stream, cnt, r_total + 2);
   if (int rc = check_launch("csr_build/zero")) return rc;
-  hipError_t e = hipSuccess;
+#endif
   int blocks = static_cast<int>((e_total + threads - 1) / threads);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(k_count, dim3(blocks), dim3(threads), 0, stream, t, keys, cnt);
@@ -304,7 +319,7 @@ extern "C" int agnn_csr_build(int n_seg, const agnn_coo_seg_t* segs, int32_t* ro
   e = hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, cnt, rowstart, static_cast<int>(r_total + 1), stream);
   if (e != hipSuccess) return fail(AGNN_ERUNTIME, "csr_build/scan: %s", hipGetErrorString(e));
   hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(threads), 0, stream, keys, static_cast<int32_t>(e_total),
-                     static_cast<uint32_t>(r_total), rowstart, cnt, vals, rowof);
+                     static_cast<uint32_t>(r_total), rowstart, cnt, vals, rowof, status);
   if (int rc = check_launch("csr_build/scatter")) return rc;
   int blocks_r = static_cast<int>((r_total + threads - 1) / threads);
   if (blocks_r > 4096) blocks_r = 4096;

@@ -68,9 +68,15 @@ __device__ __forceinline__ float gsum(float v, int gl) {
 
 template <int CH>
 __global__ __launch_bounds__(256) void k_na_fwd(NaArgs a, float* __restrict__ y, int64_t ld_y, float* __restrict__ mean_out,
-                                                float* __restrict__ rstd_out) {
+                                                float* __restrict__ rstd_out, int64_t* __restrict__ rng_used) {
   const int lane = threadIdx.x & 63;
   const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  // The (seed, step) this call draws its masks from is part of what it saves for backward: the live counter may have
+  // moved on by then (a second training forward before this one's backward).
+  if (rng_used != nullptr && a.rng != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    rng_used[0] = a.rng[0];
+    rng_used[1] = a.rng[1];
+  }
   if (row >= a.n) return;
   const bool pre = a.flags & AGNN_NA_PRE_RELU, post = a.flags & AGNN_NA_POST_RELU, drop = a.p > 0.f;
   bool on[CH];
@@ -303,7 +309,7 @@ extern "C" size_t agnn_norm_act_workspace_bytes(int32_t H) { return static_cast<
 
 extern "C" int agnn_norm_act_fwd_f32(const float* x, int64_t ld_x, const float* gamma, const float* beta, int32_t seg, int64_t n,
                                      int32_t H, float eps, float p, uint32_t flags, const int64_t* rng_state, uint32_t call_id,
-                                     float* y, int64_t ld_y, float* mean, float* rstd, agnn_stream_t stream_) {
+                                     float* y, int64_t ld_y, float* mean, float* rstd, int64_t* rng_used, agnn_stream_t stream_) {
   using namespace agnn;
   if (seg <= 0 || seg > H) seg = H;
   if (int rc = na_check("norm_act_fwd", x, ld_x, gamma, beta, n, H, seg, p, rng_state)) return rc > 0 ? AGNN_OK : rc;
@@ -311,7 +317,7 @@ extern "C" int agnn_norm_act_fwd_f32(const float* x, int64_t ld_x, const float* 
   NaArgs a{x, ld_x, gamma, beta, n, H, eps, p, flags, rng_state, call_id, seg};
   const dim3 grid(static_cast<unsigned>((n + 3) / 4)), block(256);
   hipStream_t s = static_cast<hipStream_t>(stream_);
-  AGNN_NA_DISPATCH(k_na_fwd, a, y, ld_y, mean, rstd);
+  AGNN_NA_DISPATCH(k_na_fwd, a, y, ld_y, mean, rstd, rng_used);
   return check_launch("norm_act_fwd");
 }
 

@@ -14,7 +14,7 @@ import ctypes as C
 from typing import Sequence
 
 from . import _lib
-from .linear import weight_grad, wgrad_stream
+from .linear import _steals, weight_grad, wgrad_stream
 
 MAX_ROWS = 256      # beyond this a one-hot operand is the wrong tool; fall back to the library op
 
@@ -25,6 +25,7 @@ class _SmallEmbedding(torch.autograd.Function):
         ctx.save_for_backward(idx)
         ctx.rows = weight.shape[0]
         ctx.leaf = weight.is_leaf
+        ctx.weight_ref = weight if weight.is_leaf else None
         return F.embedding(idx, weight)
 
     @staticmethod
@@ -32,7 +33,7 @@ class _SmallEmbedding(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         V = ctx.rows
         Vp = V + (V & 1)                                                   # even width for the kernel
-        with wgrad_stream(dy.device, dy, idx, active=ctx.leaf):             # optimizer-only output (linear.py)
+        with wgrad_stream(dy.device, dy, idx, active=ctx.leaf and _steals(ctx.weight_ref)):   # optimizer-only output (linear.py)
             flat_idx = idx.reshape(-1)
             onehot = (flat_idx.unsqueeze(1) == torch.arange(Vp, device=idx.device)).to(dy.dtype)   # [N, Vp]
             dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
@@ -77,6 +78,7 @@ class _EmbedCat(torch.autograd.Function):
                                               dim, out.data_ptr(), ld, _lib.stream_ptr(dev)), "agnn_embed_cat_fwd_f32")
         ctx.save_for_backward(*idc)
         ctx.meta = (n, in_x, n_tab, dim, [int(t.shape[0]) for t in tabs], all(t.is_leaf for t in tabs))
+        ctx.tab_refs = [t for t in tabs if t.is_leaf]
         return out[:, :width]
 
     @staticmethod
@@ -87,7 +89,7 @@ class _EmbedCat(torch.autograd.Function):
         dev = dout.device
         if dout.stride(1) != 1 or dout.dtype != torch.float32:
             dout = dout.float().contiguous()
-        with wgrad_stream(dev, dout, *idc, active=leaf):           # optimizer-only outputs (linear.py)
+        with wgrad_stream(dev, dout, *idc, active=leaf and all(_steals(t) for t in ctx.tab_refs)):   # optimizer-only outputs (linear.py)
             vocab = (C.c_int32 * n_tab)(*vocabs)
             dtab = torch.empty((sum(vocabs), dim), dtype=torch.float32, device=dev)
             nws = int(lib.agnn_embed_workspace_bytes(n_tab, vocab, dim))

@@ -49,17 +49,20 @@ class _NormAct(torch.autograd.Function):
         mean = torch.empty((max(n, 1) * (H // seg),), dtype=torch.float32, device=dev)
         rstd = torch.empty((max(n, 1) * (H // seg),), dtype=torch.float32, device=dev)
         rng = rng_state(dev) if p > 0 else None
+        # the (seed, step) pair this call draws from is saved with it: the live counter moves on with every training forward
+        # (models.encode -> advance_rng), and backward must regenerate THIS call's masks
+        used = torch.empty(2, dtype=torch.int64, device=dev) if p > 0 else None
         gamma, beta = _al16(gamma.contiguous()), _al16(beta.contiguous())
         _lib.check(lib.agnn_norm_act_fwd_f32(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), seg, n, H, float(eps), float(p),
                                              int(flags), _lib.ptr(rng), int(call_id), y.data_ptr(), y.stride(0), mean.data_ptr(),
-                                             rstd.data_ptr(), _lib.stream_ptr(dev)), "agnn_norm_act_fwd_f32")
-        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+                                             rstd.data_ptr(), _lib.ptr(used), _lib.stream_ptr(dev)), "agnn_norm_act_fwd_f32")
+        ctx.save_for_backward(x, gamma, beta, mean, rstd, *([used] if used is not None else []))
         ctx.cfg = (float(eps), float(p), int(flags), int(call_id), seg)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        x, gamma, beta, mean, rstd, *used = ctx.saved_tensors
         eps, p, flags, call_id, seg = ctx.cfg
         dev = dy.device
         lib = _lib.load()
@@ -70,7 +73,7 @@ class _NormAct(torch.autograd.Function):
         dbeta = torch.empty_like(beta)
         nws = int(lib.agnn_norm_act_workspace_bytes(H))
         ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-        rng = rng_state(dev) if p > 0 else None
+        rng = used[0] if p > 0 else None                     # the forward call's own (seed, step), not the live counter
         _lib.check(lib.agnn_norm_act_bwd_f32(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), seg, n, H, eps, p, flags,
                                              _lib.ptr(rng), call_id, dy.data_ptr(), dy.stride(0), mean.data_ptr(), rstd.data_ptr(),
                                              dx.data_ptr(), dx.stride(0), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), nws,

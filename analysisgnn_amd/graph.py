@@ -94,7 +94,8 @@ def build_csr(specs: Sequence[SegSpec]) -> List[Csr]:
     ws_bytes = int(lib.agnn_csr_workspace_bytes(e_total, r_total))
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
     _lib.check(lib.agnn_csr_build(len(specs), segs, rowstart.data_ptr(), col.data_ptr(), perm.data_ptr(),
-                                  ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)), "agnn_csr_build")
+                                  ws.data_ptr(), ws_bytes, _lib.status_word(dev).data_ptr(), _lib.stream_ptr(dev)),
+               "agnn_csr_build")
     out = []
     base = 0
     for s in specs:

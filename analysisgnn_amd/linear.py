@@ -49,6 +49,15 @@ def _async_ok(t: Optional[torch.Tensor]) -> bool:
     return t is None or t.is_leaf or getattr(t, "_agnn_wgrad_async", False)
 
 
+def _steals(p: Optional[torch.Tensor]) -> bool:
+    """At backward time: will autograd take this operand's gradient WITHOUT launching a kernel on the node's (main)
+    stream?  A leaf's AccumulateGrad steals a fresh contiguous tensor only when .grad is None and nothing hooks it;
+    otherwise it adds / clones on the main stream, which knows nothing about the weight-gradient stream."""
+    if p is None or not p.is_leaf:
+        return True                     # non-leaf operands were vetted by mark_wgrad_async
+    return p.grad is None and not p._backward_hooks and not getattr(p, "_post_accumulate_grad_hooks", None)
+
+
 class wgrad_stream:
     """`with wgrad_stream(dev, *inputs):` runs the body on the weight-gradient stream (after everything queued so far on
     the current stream) and keeps `inputs` alive for it; a no-op context when the overlap is disabled."""
@@ -115,7 +124,9 @@ def weight_grad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool):
     ws = torch.empty(nws, dtype=torch.uint8, device=dev)
     _lib.check(lib.agnn_wgrad_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), n, out_f, in_k, dw.data_ptr(),
                                   dw.stride(0), _lib.ptr(db), ws.data_ptr(), nws, _lib.stream_ptr(dev)), "agnn_wgrad_f32")
-    return (dw if in_k == in_f else dw[:, :in_f]), db
+    # a column-sliced view would break the layout contract of the (contiguous) parameter: AccumulateGrad would clone it on
+    # the MAIN stream without waiting for this (possibly side) stream — hand out a contiguous tensor made right here
+    return (dw if in_k == in_f else dw[:, :in_f].contiguous()), db
 
 
 class _LinearFn(torch.autograd.Function):
@@ -124,6 +135,7 @@ class _LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         ctx.wg_async = _async_ok(w) and _async_ok(b)
+        ctx.b_ref = b if (b is not None and b.is_leaf) else None
         if acc is not None:                       # y = acc + x W^T (+ b): the GEMM's beta = 1 epilogue, no separate add
             y = torch.addmm(acc, x, w.t())
             return y + b if b is not None else y
@@ -134,7 +146,8 @@ class _LinearFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            with wgrad_stream(dy.device, dy, x, active=ctx.wg_async):     # forked before dX is queued: both start at once
+            # forked before dX is queued: both start at once — only when the gradients will be STOLEN (no kernel on the main stream)
+            with wgrad_stream(dy.device, dy, x, active=ctx.wg_async and _steals(w) and _steals(ctx.b_ref)):
                 dw, db = weight_grad(dy, x, ctx.has_bias and ctx.needs_input_grad[2])
         dx = dy @ w if ctx.needs_input_grad[0] else None
         return dx, dw, db, (dy if ctx.needs_input_grad[3] else None)

@@ -297,6 +297,8 @@ def main():
     dt = time.perf_counter() - t0
     dt = dp.max_over_ranks(dt)
     assert torch.isfinite(loss).item(), "loss diverged"
+    from analysisgnn_amd import _lib
+    _lib.check_device_status(dev)                      # no CSR build of the run flagged an inconsistent index (outside the timed region)
 
     roof = roofline(args.workload, g, I, hid, layers, dev) if rank == 0 else None
     if rank == 0:

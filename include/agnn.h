@@ -88,9 +88,18 @@ typedef struct {
 
 size_t agnn_csr_workspace_bytes(int64_t e_total, int64_t total_rows);
 
+/* `status` (device int32[1], may be NULL; caller-owned, zero-initialised once, never reset by the library): incremented
+ * for every edge whose position falls outside its row — impossible when the build's own counters are intact, so a non-zero
+ * word means the workspace was disturbed while the build ran (round 1: a memset node of a captured graph that had not
+ * cleared the counters).  Nothing is written out of range in that case; the index is incomplete and agnn_check_status
+ * reports it. */
 int agnn_csr_build(int n_seg, const agnn_coo_seg_t* segs /* (host) */,
                    int32_t* rowstart, int32_t* col, int32_t* perm,
-                   void* workspace, size_t workspace_bytes, agnn_stream_t stream);
+                   void* workspace, size_t workspace_bytes, int32_t* status, agnn_stream_t stream);
+
+/* Synchronises `stream`, reads the status word and returns AGNN_ERUNTIME (with a message) when it is non-zero.  The only
+ * entry point that waits for the device: meant for tests, the end of a benchmark, or once per epoch. */
+int agnn_check_status(const int32_t* status, agnn_stream_t stream);
 
 /* rowend[i] = first position p in [rowptr[i], rowptr[i+1]) with perm[p] >= e_limit (or
  * rowptr[i+1]): the row's edges restricted to the COO prefix [0, e_limit) — PyG trim_to_layer. */
@@ -246,7 +255,10 @@ int agnn_gated_bwd_src_f32(const agnn_gated_t* g /* (host) */, const float* ds, 
  * projections, ref: models/analysis.py:429-443, :474-485; models/cadence.py:252-259).  Saves mean / rstd [n];
  * backward recomputes the ReLU masks from x and the dropout mask from the counter-based generator:
  * Philox-4x32-10(seed = rng_state[0], counter = (element, call_id, step = rng_state[1])), rng_state a DEVICE
- * int64[2] so a captured graph draws new masks when the caller bumps the step between replays.
+ * int64[2] so a captured graph draws new masks when the caller bumps the step between replays.  The forward call copies
+ * the (seed, step) pair it used into `rng_used` (DEVICE int64[2], may be NULL): hand THAT to the backward call as its
+ * rng_state — the live counter may have been bumped by another forward in between (two batches with a joint backward,
+ * gradient accumulation, the reference's memory replay: models/analysis.py:1064-1066).
  * `seg`: the statistics are taken over segments of `seg` consecutive floats of a row (seg = H: plain LayerNorm;
  * seg = 64 with H = T*64: the T task heads' LayerNorms of one note in one pass, gamma / beta being the [T*64]
  * concatenation of the per-task affines).  seg must be 4*2^k, divide 256 and divide H.  mean / rstd: [n, H/seg].
@@ -256,7 +268,7 @@ int agnn_gated_bwd_src_f32(const agnn_gated_t* g /* (host) */, const float* ds, 
 size_t agnn_norm_act_workspace_bytes(int32_t H);
 int agnn_norm_act_fwd_f32(const float* x, int64_t ld_x, const float* gamma, const float* beta, int32_t seg,
                           int64_t n, int32_t H, float eps, float p, uint32_t flags, const int64_t* rng_state, uint32_t call_id, float* y,
-                          int64_t ld_y, float* mean, float* rstd, agnn_stream_t stream);
+                          int64_t ld_y, float* mean, float* rstd, int64_t* rng_used, agnn_stream_t stream);
 int agnn_norm_act_bwd_f32(const float* x, int64_t ld_x, const float* gamma, const float* beta, int32_t seg,
                           int64_t n, int32_t H, float eps, float p, uint32_t flags, const int64_t* rng_state, uint32_t call_id,
                           const float* dy, int64_t ld_dy, const float* mean, const float* rstd, float* dx,

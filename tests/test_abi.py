@@ -53,4 +53,5 @@ def test_argument_validation_without_gpu():
     rc = lib.agnn_spmm_f32(99, rels, 4, 8, None, 8, 0, None, 0, None, 0, 0, None)
     assert rc == -22
     segs = (_lib.CooSeg * 1)()
-    assert lib.agnn_csr_build(0, segs, None, None, None, None, 0, None) == -22
+    assert lib.agnn_csr_build(0, segs, None, None, None, None, 0, None, None) == -22
+    assert lib.agnn_check_status(None, None) == -22

@@ -69,6 +69,46 @@ def test_dropout_mask_statistics_determinism_and_backward():
     assert_close(x.grad, xr.grad, 1e-4, "dx with dropout")
 
 
+def test_two_training_forwards_before_one_backward():
+    """A second training-mode forward (which bumps the device step counter: models.encode -> advance_rng) BEFORE the first
+    one's backward — two batches with a joint backward, gradient accumulation, the reference's memory replay
+    (models/analysis.py:1064-1066, :1327-1366).  The first call's backward must regenerate the masks of ITS forward: the
+    (seed, step) pair travels with the call's saved state, not with the live counter."""
+    from analysisgnn_amd import fused
+    torch.manual_seed(1)
+    H, N, p = 256, 1000, 0.3
+    ln = nn.LayerNorm(H).to(DEV)
+    x = torch.randn(N, H, device=DEV)
+    g = torch.randn(N, H, device=DEV)
+
+    def grads(second_forward_in_between):
+        xa = x.clone().requires_grad_(True)
+        ln.zero_grad()
+        ya = fused._NormAct.apply(xa, ln.weight, ln.bias, ln.eps, p, fused.POST_RELU, 21)
+        if second_forward_in_between:
+            fused.advance_rng(x.device)                             # the next step's forward ...
+            xb = x.clone().requires_grad_(True)
+            yb = fused._NormAct.apply(xb, ln.weight, ln.bias, ln.eps, p, fused.POST_RELU, 21)
+            assert not torch.equal(ya, yb)                          # ... draws other masks
+        (ya * g).sum().backward()
+        return ya.detach().clone(), xa.grad.clone(), ln.weight.grad.clone(), ln.bias.grad.clone()
+
+    step0 = fused.rng_state(x.device).clone()
+    one = grads(False)
+    fused.rng_state(x.device).copy_(step0)                          # same starting step for the second scenario
+    two = grads(True)
+    for a, b, name in zip(one, two, ("y", "dx", "dgamma", "dbeta")):
+        assert torch.equal(a, b), name
+    # and the gradient is the one of the mask that was applied: zero exactly where the output was dropped
+    dropped = (one[0] == 0)
+    assert float(one[1][dropped].abs().max()) >= 0.0               # (LayerNorm couples a row: dx is dense; checked via dgamma below)
+    xr = x.clone().requires_grad_(True)
+    base = F.relu(F.layer_norm(xr, (H,), ln.weight.detach(), ln.bias.detach(), ln.eps))
+    mask = ((one[0] != 0) | ~(base.detach() > 0)).float() / (1 - p)
+    (base * mask * g).sum().backward()
+    assert_close(one[1], xr.grad, 1e-4, "dx of the first call")
+
+
 def test_fused_sequential_matches_sequential_in_eval():
     from analysisgnn_amd.fused import FusedSequential
     torch.manual_seed(1)

@@ -164,6 +164,10 @@ def test_single_stream_captured_step_is_stable_over_many_replays():
             cg.replay()
         torch.cuda.synchronize()
         assert torch.equal(flat.flat, g_eager), float((flat.flat - g_eager).abs().max())
+        # no CSR build of any replay met a position outside its row (the device status word the builds share): a
+        # recurrence of the stale-counter state raises here instead of passing on an index with missing edges
+        from analysisgnn_amd import _lib
+        _lib.check_device_status(dev)
     finally:
         graph.index_cache_enabled = was
         _HybridMixin.overlap_sequence_branch = was_overlap

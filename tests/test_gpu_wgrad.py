@@ -90,6 +90,36 @@ def test_wgrad_stream_overlap_gives_identical_gradients():
     assert torch.equal(grads[0], grads[1])
 
 
+def test_wgrad_overlap_with_preallocated_grads_stays_on_the_main_stream():
+    """Parameters whose .grad already exists (FlatGradBuffer(views=True), gradient accumulation) make AccumulateGrad ADD on
+    the main stream, which does not wait for the weight-gradient stream: such layers must not fork (linear._steals).
+    The 153-wide note input (weight gradient computed on 154 columns) must come back as a contiguous tensor."""
+    from analysisgnn_amd import dp, linear
+    torch.manual_seed(0)
+    dev = "cuda:0"
+    lin = linear.Linear(153, 64).to(dev)
+    buf = torch.zeros(5000, 156, device=dev)
+    buf[:, :153] = torch.randn(5000, 153, device=dev)
+    x = buf[:, :153]
+    g = torch.randn(5000, 64, device=dev)
+    ref_w = g.t() @ x
+    ref_b = g.sum(0)
+    for pre in (False, True):
+        lin.weight.grad = torch.zeros_like(lin.weight) if pre else None
+        lin.bias.grad = torch.zeros_like(lin.bias) if pre else None
+        dp.enable_wgrad_overlap(True)
+        try:
+            assert linear._steals(lin.weight) == (not pre)
+            lin(x).backward(g)
+            linear.join_wgrad()
+            torch.cuda.synchronize()
+        finally:
+            dp.enable_wgrad_overlap(False)
+        assert lin.weight.grad.is_contiguous()
+        assert_close(lin.weight.grad, ref_w, 1e-4, f"dW (pre-allocated grad: {pre})")
+        assert_close(lin.bias.grad, ref_b, 1e-4, "db")
+
+
 def test_weight_grad_odd_width_with_padded_rows():
     """in = 153 (25 features + two 64-wide embeddings) on rows padded to 156 floats: served by the kernel on 154 columns."""
     from analysisgnn_amd import linear
