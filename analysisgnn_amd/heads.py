@@ -120,6 +120,114 @@ def grouped_projection(a: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tenso
     return _GroupedProj.apply(a, w, b, _offs_tensor(offs, a.device), tuple(int(o) for o in offs), int(K))
 
 
+class _GroupedInProj(torch.autograd.Function):
+    """The mirror image of the grouped projection: group g reads ITS OWN C_g input columns and writes K output columns,
+        out[:, g*K:(g+1)*K] = x[:, offs[g]:offs[g+1]] @ w[offs[g]:offs[g+1]]            x [N, sum C], w [sum C, K]
+    (the 21 `clf_proj_layers[task][0] = Linear(C_t, o/2)` of the logit-fusion path, models/analysis.py:499-505, :552).
+    Same three kernels with the roles swapped: forward = k_gproj_dx, input gradient = k_gproj_fwd, weight gradient =
+    k_gproj_dw."""
+
+    @staticmethod
+    def forward(ctx, x, w, offs_t, offs, K):
+        dev = _lib.require_gpu(x, w, offs_t)
+        x = _lib.f32c(x)
+        w = _lib.f32c(w)
+        if w.data_ptr() % 16:
+            w = w.clone()
+        G = len(offs) - 1
+        sum_c = offs[-1]
+        tiles = sum((offs[i + 1] - offs[i] + 31) // 32 for i in range(G))
+        N = x.shape[0]
+        out = torch.empty((N, G * K), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        _lib.check(lib.agnn_gproj_bwd_f32(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), w.data_ptr(), offs_t.data_ptr(), G, K,
+                                          tiles, sum_c, N, out.data_ptr(), out.stride(0), None, None, None, 0, _lib.stream_ptr(dev)),
+                   "agnn_gproj_bwd_f32(dx as forward)")
+        ctx.save_for_backward(x, w, offs_t)
+        ctx.meta = (G, K, tiles, sum_c)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w, offs_t = ctx.saved_tensors
+        G, K, tiles, sum_c = ctx.meta
+        dev = x.device
+        dout = _lib.f32c(dout)
+        N = x.shape[0]
+        lib = _lib.load()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.check(lib.agnn_gproj_fwd_f32(dout.data_ptr(), dout.stride(0), w.data_ptr(), None, offs_t.data_ptr(), G, K, tiles, N,
+                                              dx.data_ptr(), dx.stride(0), _lib.stream_ptr(dev)), "agnn_gproj_fwd_f32(as input gradient)")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            nws = int(lib.agnn_gproj_workspace_bytes(N, sum_c, K, tiles))
+            ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=dev)
+            _lib.check(lib.agnn_gproj_bwd_f32(x.data_ptr(), x.stride(0), dout.data_ptr(), dout.stride(0), w.data_ptr(), offs_t.data_ptr(),
+                                              G, K, tiles, sum_c, N, None, 0, dw.data_ptr(), None, ws.data_ptr(), nws,
+                                              _lib.stream_ptr(dev)), "agnn_gproj_bwd_f32(dw)")
+        return dx, dw, None, None, None
+
+
+def grouped_in_projection(x: torch.Tensor, w: torch.Tensor, offs: Sequence[int], K: int) -> torch.Tensor:
+    """out[:, g*K:(g+1)*K] = x[:, offs[g]:offs[g+1]] @ w[offs[g]:offs[g+1]] for every group g (w = the groups' [C_g, K]
+    matrices stacked along rows)."""
+    return _GroupedInProj.apply(x, w, _offs_tensor(offs, x.device), tuple(int(o) for o in offs), int(K))
+
+
+class CrossTaskTransformer(nn.Module):
+    """models/analysis.py:408-418: `LayerNorm(x + MultiheadAttention(x, x, x))` over the T task tokens of every note
+    (batch_first, `num_heads` heads, dropout on the attention probabilities).  Same parameters and names
+    (`multihead_attn.in_proj_weight / in_proj_bias / out_proj.*`, `norm.*`); the schedule differs: the packed in-projection
+    and the out-projection are single [N*T, E] GEMMs on `linear` (weight gradients on the split-N MFMA kernel), the
+    T x T attention of all notes and heads is one scaled-dot-product call, and residual + LayerNorm is one fused launch."""
+
+    def __init__(self, proj_dim, num_heads=4, dropout=0.1):
+        super().__init__()
+        self.multihead_attn = nn.MultiheadAttention(proj_dim, num_heads, dropout=dropout, batch_first=True)
+        self.norm = nn.LayerNorm(proj_dim)
+
+    def forward(self, task_projections):
+        from .fused import norm_act
+        mha = self.multihead_attn
+        N, T, E = task_projections.shape
+        h = mha.num_heads
+        x2 = task_projections.reshape(N * T, E)
+        qkv = linear(x2, mha.in_proj_weight, mha.in_proj_bias).view(N, T, 3, h, E // h)
+        q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))                      # [N, h, T, E/h]
+        att = F.scaled_dot_product_attention(q, k, v, dropout_p=mha.dropout if self.training else 0.0)
+        att = att.transpose(1, 2).reshape(N * T, E)
+        out = linear(att, mha.out_proj.weight, mha.out_proj.bias, acc=x2)                # residual as the GEMM's beta = 1 epilogue
+        return norm_act(out, self.norm).view(N, T, E)
+
+
+def fused_logit_fusion(proj_layers: nn.ModuleDict, transformer: nn.Module, fusion_layers: nn.ModuleDict, logits: torch.Tensor,
+                       offs: Sequence[int], tasks: Sequence[str], training: bool) -> torch.Tensor:
+    """The reference's logit-fusion epilogue (models/analysis.py:550-565) on the side-by-side logits [N, sum C]:
+      proj_t   = LayerNorm(ReLU(Linear_t(raw_t)))             21 x clf_proj_layers  -> ONE grouped launch + one fused norm
+      enhanced = LayerNorm(proj + MHA(proj, proj, proj))      CrossTaskTransformer over the T task tokens of every note
+      refined_t = Linear_t(enhanced[:, t])                    21 x fusion_layers    -> ONE grouped launch
+    Returns the refined logits in the same [N, sum C] layout.  Parameters stay in the reference's modules
+    (`clf_proj_layers.<task>.{0,2}`, `cross_task_transformer.multihead_attn.*`, `.norm`, `fusion_layers.<task>`)."""
+    T = len(tasks)
+    pm = [proj_layers[t] for t in tasks]
+    K = pm[0][0].out_features
+    N = logits.shape[0]
+    if not (logits.is_cuda and K in GPROJ_K and T <= _lib.MAX_SEG):
+        raise _lib.AgnnError(f"logit fusion: projection width {K} / {T} tasks not supported by the grouped kernels")
+    Wp = torch.cat([m[0].weight.t() for m in pm], dim=0)                                 # [sum C, K]
+    bp = cat_rows([m[0].bias for m in pm])                                                # [T*K]
+    a = grouped_in_projection(logits, Wp, offs, K) + bp
+    gamma = stack_rows([m[2].weight for m in pm])
+    beta = stack_rows([m[2].bias for m in pm])
+    a = grouped_norm_act(a.view(N, T, K), gamma, beta, pm[0][2].eps, pre_relu=True)       # [N, T, K]
+    enh = transformer(a)                                                                  # [N, T, K]
+    Wf = cat_rows([fusion_layers[t].weight for t in tasks])                               # [sum C, K]
+    bf = cat_rows([fusion_layers[t].bias for t in tasks])
+    return grouped_projection(enh.reshape(N, T * K), Wf, bf, offs, K)
+
+
 class _MultiTaskCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels, offs_t, eps: float, ignore_index: int, full_cover: bool = False):

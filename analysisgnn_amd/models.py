@@ -14,7 +14,7 @@ from . import _lib, ops
 from .encoders import HybridGNN, MetricalGNN
 from .fused import FusedSequential, advance_rng
 from .embedding import embed_cat
-from .heads import fused_head_logits
+from .heads import CrossTaskTransformer, fused_head_logits, fused_logit_fusion
 from .linear import Linear
 from .graph import SegSpec, build_csr
 
@@ -47,10 +47,14 @@ def _input_mlp(i, h, dropout):
 
 class TorchAnalysisGNN(nn.Module):
     def __init__(self, metadata, in_channels, hidden_channels, out_channels, task_dict, num_layers, dropout=0.5,
-                 use_jk=True, logit_fusion=False, use_rnn=False, encoder_type="hybridgnn"):
+                 use_jk=True, logit_fusion=True, use_rnn=False, encoder_type="hybridgnn"):
+        """Same defaults as the reference constructor (models/analysis.py:422: `logit_fusion=True`; the training CLI
+        passes False unless --logit_fusion is given, train/train_analysisgnn.py:97)."""
         super().__init__()
-        if logit_fusion or use_rnn:
-            raise NotImplementedError("logit_fusion / use_rnn are outside the hot-path scope (SURVEY.md §8f)")
+        if use_rnn:
+            # the reference's own use_rnn branch cannot run (SURVEY.md App. A.7: rnn_mlp = Linear(o, o/2) -> LayerNorm(o),
+            # GRU output 2*o wide into LayerNorm(o), models/analysis.py:512-521): there is no behaviour to reproduce
+            raise NotImplementedError("use_rnn=True: the reference branch is shape-inconsistent (models/analysis.py:512-521)")
         self.pitch_embedding = nn.Embedding(35, 64)
         self.key_embedding = nn.Embedding(15, 64)
         self.logit_fusion = logit_fusion
@@ -78,6 +82,12 @@ class TorchAnalysisGNN(nn.Module):
         self.clf_dict = nn.ModuleDict({
             t: nn.Sequential(nn.Linear(o, o // 2), nn.ReLU(), nn.LayerNorm(o // 2), nn.Linear(o // 2, c))
             for t, c in task_dict.items()})
+        if logit_fusion:                                        # models/analysis.py:497-511
+            self.clf_proj_layers = nn.ModuleDict({
+                t: nn.Sequential(nn.Linear(c, o // 2), nn.ReLU(), nn.LayerNorm(o // 2)) for t, c in task_dict.items()})
+            self.cross_task_transformer = CrossTaskTransformer(o // 2, num_heads=4, dropout=dropout)
+            self.fusion_layers = nn.ModuleDict({t: nn.Linear(o // 2, c) for t, c in task_dict.items()})
+        self.rnn, self.rnn_norm, self.rnn_mlp = nn.Identity(), nn.Identity(), nn.Identity()   # use_rnn=False, :522-525
 
     def adjacent_parameter_groups(self):
         """Parameters the fused schedule consumes concatenated (heads.fused_head_logits: per-layer cats over the tasks;
@@ -117,6 +127,9 @@ class TorchAnalysisGNN(nn.Module):
     def forward_clf_fused(self, x, tasks=None):
         tasks = list(self.clf_dict.keys() if tasks is None else tasks)
         logits, offs = fused_head_logits(self.clf_dict, x, tasks)
+        if self.logit_fusion:                                   # models/analysis.py:550-565: refined logits replace the raw ones
+            logits = fused_logit_fusion(self.clf_proj_layers, self.cross_task_transformer, self.fusion_layers, logits, offs,
+                                        tasks, self.training)
         return logits, offs, tasks
 
     def forward(self, pitch_spelling, key_signature, x_dict, edge_index_dict, batch_dict, batch_size,

@@ -15,7 +15,7 @@ I = torch_inputs(g, bench.IN_CH, dev, 0)
 labels = bench.make_labels(I["batch_size"], dev, 1)
 label_mat = torch.stack([labels[t] for t in bench.TASK_DICT])
 torch.manual_seed(0)
-model = TorchAnalysisGNN(g.metadata(), bench.IN_CH, bench.H, bench.OUT, bench.TASK_DICT, bench.LAYERS, dropout=0.3, use_jk=False).to(dev).train()
+model = TorchAnalysisGNN(g.metadata(), bench.IN_CH, bench.H, bench.OUT, bench.TASK_DICT, bench.LAYERS, dropout=0.3, use_jk=False, logit_fusion=False).to(dev).train()
 flat = dp.FlatGradBuffer(model.parameters())
 opt = torch.optim.AdamW(model.parameters(), lr=5e-3, weight_decay=5e-3, foreach=True)
 graph.index_cache_enabled = False

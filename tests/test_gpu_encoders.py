@@ -103,7 +103,7 @@ def test_analysis_model_logits(enc):
     H, L = 32, 3
     torch.manual_seed(2)
     m = TorchAnalysisGNN(g.metadata(), in_channels=25, hidden_channels=H, out_channels=16, task_dict=tasks,
-                         num_layers=L, dropout=0.0, use_jk=False, encoder_type=enc).train()
+                         num_layers=L, dropout=0.0, use_jk=False, logit_fusion=False, encoder_type=enc).train()
     P = _cpu_params(m)
     m = m.to(DEV)
     I = torch_inputs(g, in_channels=25, seed=3)

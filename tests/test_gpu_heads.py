@@ -66,7 +66,7 @@ def test_model_forward_clf_is_dict_of_views():
     from analysisgnn_amd.models import TorchAnalysisGNN
     from analysisgnn_amd.synth import make_batch
     g = make_batch(1, 30)
-    m = TorchAnalysisGNN(g.metadata(), 25, 32, 16, {"a": 3, "b": 7}, 2, dropout=0.0, use_jk=False).to(DEV)
+    m = TorchAnalysisGNN(g.metadata(), 25, 32, 16, {"a": 3, "b": 7}, 2, dropout=0.0, use_jk=False, logit_fusion=False).to(DEV)
     x = torch.randn(11, 16, device=DEV)
     out = m.forward_clf(x)
     assert list(out) == ["a", "b"] and out["a"].shape == (11, 3) and out["b"].shape == (11, 7)
@@ -180,3 +180,91 @@ def test_training_loss_label_checks():
     total, per = training_loss(logits, offs, labels, feat, 0.0, task_params=m.params, ce_scale=1.0)
     assert_close(out["total"].detach(), total.detach(), 1e-5, "module total")
     assert_close(torch.stack([out["a"], out["b"]]).detach(), per, 1e-6, "module per-task")
+
+
+@pytest.mark.parametrize("K,classes,N", [(64, [2, 185, 33, 32, 1, 64, 7], 1003), (32, [5, 40], 70), (64, [12] * 21, 4100)])
+def test_grouped_in_projection_matches_per_task_linear(K, classes, N):
+    """The mirrored grouped projection (group g reads its own C_g columns, writes K: the 21 `clf_proj_layers[task][0]` of the
+    logit-fusion path, models/analysis.py:499-505) against per-task float64 matmuls: forward, dx, dw."""
+    from analysisgnn_amd.heads import grouped_in_projection
+    torch.manual_seed(1)
+    G = len(classes)
+    offs = [0]
+    for c in classes:
+        offs.append(offs[-1] + c)
+    x = torch.randn(N, offs[-1])
+    w = torch.randn(offs[-1], K) * 0.2
+    gout = torch.randn(N, G * K)
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    ref = torch.cat([x64[:, offs[g]:offs[g + 1]] @ w64[offs[g]:offs[g + 1]] for g in range(G)], dim=1)
+    ref.backward(gout.double())
+    xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    out = grouped_in_projection(xg, wg, offs, K)
+    out.backward(gout.to(DEV))
+    assert_close(out, ref.float(), 1e-5, "out")
+    assert_close(xg.grad, x64.grad.float(), 1e-5, "dx")
+    assert_close(wg.grad, w64.grad.float(), 1e-5, "dw")
+
+
+class _RefCrossTaskTransformer(torch.nn.Module):
+    """The reference's module verbatim in behaviour (models/analysis.py:408-418): nn.MultiheadAttention + residual + LayerNorm."""
+
+    def __init__(self, proj_dim, num_heads=4, dropout=0.1):
+        super().__init__()
+        self.multihead_attn = torch.nn.MultiheadAttention(proj_dim, num_heads, dropout=dropout, batch_first=True)
+        self.norm = torch.nn.LayerNorm(proj_dim)
+
+    def forward(self, x):
+        attended, _ = self.multihead_attn(x, x, x)
+        return self.norm(x + attended)
+
+
+@pytest.mark.parametrize("subset", [None, ["localkey", "cadence", "romanNumeral"]])
+def test_logit_fusion_matches_reference_wiring(subset):
+    """forward_clf with logit_fusion=True (the reference constructor's default, models/analysis.py:422) against the same
+    computation written as the reference writes it (:550-565): per-task Linear -> ReLU -> LayerNorm projections of the raw
+    logits, stack, nn.MultiheadAttention over the task tokens + residual + LayerNorm, per-task fusion Linear.  Float64 CPU
+    reference with the model's own state_dict; logits and every parameter gradient within 1e-4."""
+    from analysisgnn_amd.models import TorchAnalysisGNN
+    from analysisgnn_amd.synth import make_batch
+    import torch.nn as nn
+    tasks = {"cadence": 4, "localkey": 50, "tonkey": 50, "quality": 15, "romanNumeral": 185, "section": 2}
+    g = make_batch(1, 30)
+    torch.manual_seed(5)
+    o = 128
+    m = TorchAnalysisGNN(g.metadata(), 25, 32, o, tasks, 2, dropout=0.0, use_jk=False, logit_fusion=True).train()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    # reference-side modules, float64
+    clf = nn.ModuleDict({t: nn.Sequential(nn.Linear(o, o // 2), nn.ReLU(), nn.LayerNorm(o // 2), nn.Linear(o // 2, c)) for t, c in tasks.items()})
+    proj = nn.ModuleDict({t: nn.Sequential(nn.Linear(c, o // 2), nn.ReLU(), nn.LayerNorm(o // 2)) for t, c in tasks.items()})
+    ctt = _RefCrossTaskTransformer(o // 2, 4, 0.0)
+    fus = nn.ModuleDict({t: nn.Linear(o // 2, c) for t, c in tasks.items()})
+    for name, mod in (("clf_dict", clf), ("clf_proj_layers", proj), ("cross_task_transformer", ctt), ("fusion_layers", fus)):
+        mod.load_state_dict({k[len(name) + 1:]: v for k, v in sd.items() if k.startswith(name + ".")})
+        mod.double()
+    N = 2500
+    x = torch.randn(N, o)
+    use = list(tasks) if subset is None else subset
+    xr = x.double().requires_grad_(True)
+    raw = {t: clf[t](xr) for t in use}                                                   # :549
+    pl = {t: proj[t](raw[t]) for t in raw}                                               # :552
+    names = list(pl)
+    enh = ctt(torch.stack([pl[t] for t in names], dim=1))                                # :555-559
+    ref = {t: fus[t](enh[:, i]) for i, t in enumerate(names)}                            # :562-565
+    gout = {t: torch.randn(N, tasks[t]) for t in use}
+    sum((ref[t] * gout[t].double()).sum() for t in use).backward()
+    m = m.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    out = m.forward_clf(xg, None if subset is None else subset)
+    assert list(out) == use
+    sum((out[t] * gout[t].to(DEV)).sum() for t in use).backward()
+    for t in use:
+        assert_close(out[t], ref[t].float(), 1e-4, f"refined logits {t}")
+    assert_close(xg.grad, xr.grad.float(), 1e-4, "dx")
+    got = dict(m.named_parameters())
+    for name, mod in (("clf_dict", clf), ("clf_proj_layers", proj), ("cross_task_transformer", ctt), ("fusion_layers", fus)):
+        for k, p in mod.named_parameters():
+            if p.grad is None:
+                assert got[f"{name}.{k}"].grad is None or float(got[f"{name}.{k}"].grad.abs().max()) == 0.0, k
+                continue
+            assert_close(got[f"{name}.{k}"].grad, p.grad.float(), 1e-4, f"d {name}.{k}")

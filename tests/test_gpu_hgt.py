@@ -124,7 +124,7 @@ def test_hybrid_hgt_encoder(kind):
     H, L = 32, 3
     torch.manual_seed(0)
     m = HybridHGT(metadata=g.metadata(), input_channels=H, hidden_channels=H, num_layers=L, heads=4, dropout=0.0,
-                  use_jk=False).train()
+                  use_jk=False, logit_fusion=False).train()
     P = _cpu_params(m)
     m = m.to(DEV)
     I = torch_inputs(g, in_channels=H, seed=1)
@@ -153,7 +153,7 @@ def test_analysis_model_hgt_logits():
     tasks = {"cadence": 4, "localkey": 50, "romanNumeral": 185}
     torch.manual_seed(3)
     m = TorchAnalysisGNN(g.metadata(), in_channels=25, hidden_channels=32, out_channels=16, task_dict=tasks, num_layers=3,
-                         dropout=0.0, use_jk=False, encoder_type="hgt").train()
+                         dropout=0.0, use_jk=False, logit_fusion=False, encoder_type="hgt").train()
     P = {k: v.detach().clone() for k, v in m.state_dict().items()}
     m = m.to(DEV)
     I = torch_inputs(g, in_channels=25, seed=4)

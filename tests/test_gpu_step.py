@@ -19,7 +19,7 @@ def test_graph_replay_equals_eager_step_and_is_reproducible():
     labels = torch.stack([torch.randint(0, c, (I["batch_size"],), generator=torch.Generator().manual_seed(i)).to(dev)
                           for i, c in enumerate(tasks.values())])
     torch.manual_seed(0)
-    model = TorchAnalysisGNN(g.metadata(), 25, 256, 128, tasks, 3, dropout=0.0, use_jk=False).to(dev).train()
+    model = TorchAnalysisGNN(g.metadata(), 25, 256, 128, tasks, 3, dropout=0.0, use_jk=False, logit_fusion=False).to(dev).train()
     flat = dp.FlatGradBuffer(model.parameters(), views=False)
     was = graph.index_cache_enabled
     graph.index_cache_enabled = False
@@ -81,7 +81,7 @@ def test_adjacent_parameter_layout_gives_the_same_step():
 
     def build():
         torch.manual_seed(0)
-        return TorchAnalysisGNN(g.metadata(), 25, 256, 128, tasks, 3, dropout=0.0, use_jk=False).to(dev).train()
+        return TorchAnalysisGNN(g.metadata(), 25, 256, 128, tasks, 3, dropout=0.0, use_jk=False, logit_fusion=False).to(dev).train()
 
     def step(model):
         x = model.encode(I["pitch_spelling"], I["key_signature"], I["x_dict"], I["edge_index_dict"], I["batch_dict"],
@@ -131,7 +131,7 @@ def test_single_stream_captured_step_is_stable_over_many_replays():
     labels = torch.stack([torch.randint(0, c, (I["batch_size"],), generator=torch.Generator().manual_seed(i)).to(dev)
                           for i, c in enumerate(tasks.values())])
     torch.manual_seed(0)
-    model = TorchAnalysisGNN(g.metadata(), 25, 256, 128, tasks, 3, dropout=0.0, use_jk=False).to(dev).train()
+    model = TorchAnalysisGNN(g.metadata(), 25, 256, 128, tasks, 3, dropout=0.0, use_jk=False, logit_fusion=False).to(dev).train()
     params, tight = dp.plan_parameters(model)
     flat = dp.FlatGradBuffer(params, views=False, tight=tight)
     was, was_overlap = graph.index_cache_enabled, _HybridMixin.overlap_sequence_branch

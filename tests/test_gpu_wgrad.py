@@ -70,7 +70,7 @@ def test_wgrad_stream_overlap_gives_identical_gradients():
     grads = []
     for overlap in (False, True):
         torch.manual_seed(0)
-        model = TorchAnalysisGNN(g.metadata(), 25, 256, 128, tasks, 2, dropout=0.0, use_jk=False).to("cuda:0").train()
+        model = TorchAnalysisGNN(g.metadata(), 25, 256, 128, tasks, 2, dropout=0.0, use_jk=False, logit_fusion=False).to("cuda:0").train()
         flat = dp.FlatGradBuffer(model.parameters(), views=False)
         dp.enable_wgrad_overlap(overlap)
         try:
