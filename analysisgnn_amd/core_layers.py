@@ -134,10 +134,50 @@ class SageConvScatter(nn.Module):
         return self.linear(torch.cat([features, s], dim=-1))
 
 
-def _make_reduction(reduction: str):
-    if reduction not in ("mean", "sum"):
-        raise NotImplementedError(f"reduction={reduction!r}: only 'mean' and 'sum' run on the HIP path")
-    return reduction
+class HeteroAttention(nn.Module):
+    """core/hgnn.py:8-23 (the `lstm` reduction of the hetero wrappers, :41, :115, :462): on the relation stack x [R, N, H]
+    the batch_first bi-LSTM takes the R relations as the batch and the N NODES as the sequence, the softmax runs over the
+    last axis of [R, N] (the nodes), and the result is the weighted sum over relations — reproduced literally.  The LSTM
+    is the library's (MIOpen); hidden (R*H)//2 per direction."""
+
+    def __init__(self, n_hidden, n_layers):
+        super().__init__()
+        self.lstm = nn.LSTM(n_hidden, (n_layers * n_hidden) // 2, bidirectional=True, batch_first=True)
+        self.att = nn.Linear(2 * ((n_layers * n_hidden) // 2), 1)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.lstm.reset_parameters()
+        nn.init.xavier_uniform_(self.att.weight, gain=nn.init.calculate_gain("relu"))
+
+    def forward(self, x):
+        alpha, _ = self.lstm(x)
+        alpha = torch.softmax(self.att(alpha).squeeze(-1), dim=-1)
+        return (x * alpha.unsqueeze(-1)).sum(dim=0)
+
+
+def _make_reduction(reduction: str, out_features: Optional[int] = None, n_rel: Optional[int] = None, allow_none: bool = False):
+    """The reductions of core/hgnn.py:30-46 / :102-116 / :451-464 that run in the reference: 'mean', 'sum', 'lstm'
+    (HeteroAttention, a module: returned as such so that its parameters sit under `reduction.*` as in the reference) and,
+    for the ResGated wrapper only, 'none'.  'max' / 'min' hand a (values, indices) pair to `.to()` and 'concat' calls
+    torch.cat on a tensor: both raise in the reference, so they raise here as well."""
+    if reduction in ("mean", "sum"):
+        return reduction
+    if reduction == "lstm":
+        return HeteroAttention(out_features, n_rel)
+    if reduction == "none" and allow_none:
+        return reduction
+    raise NotImplementedError(f"reduction={reduction!r}: not runnable in the reference either (core/hgnn.py:108-112)")
+
+
+def _reduce_stack(reduction, st: torch.Tensor) -> torch.Tensor:
+    if isinstance(reduction, nn.Module):
+        return reduction(st)
+    if reduction == "mean":
+        return st.mean(dim=0)
+    if reduction == "sum":
+        return st.sum(dim=0)
+    return st                                            # 'none'
 
 
 class HeteroSageConvLayer(nn.Module):
@@ -150,14 +190,39 @@ class HeteroSageConvLayer(nn.Module):
         self.out_features = out_features
         self.in_features = in_features
         self.etypes = etypes
-        self.reduction = _make_reduction(reduction)
+        self.reduction = _make_reduction(reduction, out_features, len(etypes))
         self.conv = nn.ModuleDict({k: SageConvScatter(in_features, out_features, bias=bias) for k in etypes.keys()})
 
     def reset_parameters(self):
         for c in self.conv.values():
             c.reset_parameters()
 
+    def _per_relation(self, x, tix: TypedIndex):
+        """[R, N, out]: every relation's own output (needed by the reductions that are not linear in the slots).  Same
+        fused aggregation; the output projection is one batched GEMM over the relations."""
+        names = tix.names
+        R = len(names)
+        Fin = self.in_features
+        if Fin % 4 != 0:
+            raise _lib.AgnnError("HeteroSageConvLayer on HIP needs in_features % 4 == 0")
+        convs = [self.conv[k] for k in names]
+        Wn = torch.cat([c.neigh_linear.weight for c in convs], dim=0)
+        bn = torch.cat([c.neigh_linear.bias for c in convs]) if convs[0].neigh_linear.bias is not None else None
+        Hcat = F.linear(x, Wn, bn)
+        srcs = [Hcat[:, r * Fin:(r + 1) * Fin] for r in range(R)]
+        spec = ops.AggSpec(fwd=tix.fwd, bwd=tix.bwd, src_id=list(range(R)), n_rows=x.shape[0], mean=True, shared_slot=False)
+        S = ops.aggregate(spec, srcs, self_t=x)
+        S = torch.where(tix.empty.repeat_interleave(Fin).unsqueeze(0), Hcat, S)          # empty relation: s_r = h_r
+        W = torch.stack([c.linear.weight for c in convs])                                 # [R, out, 2F]
+        xs = torch.cat([x.unsqueeze(0).expand(R, -1, -1), S.view(-1, R, Fin).transpose(0, 1)], dim=-1)   # [R, N, 2F]
+        out = torch.bmm(xs, W.transpose(1, 2))
+        if convs[0].linear.bias is not None:
+            out = out + torch.stack([c.linear.bias for c in convs]).unsqueeze(1)
+        return out
+
     def _fused(self, x, tix: TypedIndex):
+        if not isinstance(self.reduction, str) or self.reduction == "none":
+            return _reduce_stack(self.reduction, HeteroSageConvLayer._per_relation(self, x, tix))
         names = tix.names
         R = len(names)
         Fin = self.in_features
@@ -361,10 +426,19 @@ class _HeteroPerRelation(nn.Module):
                 if edge_features is not None and conv.in_edge_features is not None:
                     c = conv.W5(edge_features)           # all edges; the kernel reads the rows of this relation's edges
                 outs.append(conv.forward_csr(x, tix.fwd[r], tix.bwd[r], c))
+            elif isinstance(conv, (RelEdgeConv, SageConvScatter)):
+                # per-edge messages of data-dependent size: the relation's edges are compacted as the reference does
+                # (boolean mask, core/hgnn.py:481-483 — a host sync; this block is off the benchmarked configurations)
+                if isinstance(edge_index, dict):
+                    sub, ef = edge_index[tix.names[r]], None
+                else:
+                    m = edge_type == self.etypes[tix.names[r]]
+                    sub = edge_index[:, m]
+                    ef = edge_features[m] if edge_features is not None else None
+                outs.append(conv(x, sub, ef))
             else:
                 raise NotImplementedError(f"{type(conv).__name__} inside a hetero wrapper is not on the HIP path")
-        st = torch.stack(outs, dim=0)
-        return st.mean(dim=0) if self.reduction == "mean" else st.sum(dim=0)
+        return _reduce_stack(self.reduction, torch.stack(outs, dim=0))
 
 
 class HeteroResGatedGraphConvLayer(_HeteroPerRelation):
@@ -373,7 +447,7 @@ class HeteroResGatedGraphConvLayer(_HeteroPerRelation):
     def __init__(self, in_features, out_features, etypes, bias=True, reduction="mean"):
         super().__init__()
         self.out_features, self.in_features, self.etypes = out_features, in_features, etypes
-        self.reduction = _make_reduction(reduction)
+        self.reduction = _make_reduction(reduction, out_features, len(etypes), allow_none=True)
         self.conv = nn.ModuleDict({k: ResGatedGraphConv(in_features, out_features, bias=bias) for k in etypes.keys()})
 
     def reset_parameters(self):
@@ -391,7 +465,7 @@ class HeteroConv(_HeteroPerRelation):
                  reduction="mean"):
         super().__init__()
         self.out_features, self.in_features, self.etypes = out_features, in_features, etypes
-        self.reduction = _make_reduction(reduction)
+        self.reduction = _make_reduction(reduction, out_features, len(etypes))
         self.conv = nn.ModuleDict({k: module(in_features, out_features, bias=bias, in_edge_features=in_edge_features)
                                    for k in etypes.keys()})
 
@@ -400,6 +474,61 @@ class HeteroConv(_HeteroPerRelation):
             c.reset_parameters()
 
     def forward(self, x, edge_index, edge_type, edge_features=None):
+        return self._run(x, edge_index, edge_type, edge_features)
+
+
+class RelEdgeConv(nn.Module):
+    """core/gnn.py:79-106.  h = W_n x + b;  e_ij = |h_i - h_j| unless edge features are given;  m_ij = W_e [h_j || e_ij] + b_e;
+    s_i = (h_i + sum_{(i,j)} m_ij) / max(deg_i, 1)  (scatter onto edge row 0 with `out=h.clone()`, mean);  z = W [x || s] + b.
+    The per-edge messages [E, F] are built with library gathers / one GEMM; the scatter-mean with the `out=` numerator
+    runs on the gather-reduce kernel (`scatter.scatter`)."""
+
+    def __init__(self, in_node_features, out_features, bias=True, in_edge_features=None):
+        super().__init__()
+        self.neigh_linear = nn.Linear(in_node_features, in_node_features, bias=bias)
+        self.edge_linear = nn.Linear(in_node_features * 2 if in_edge_features is None else in_node_features + in_edge_features,
+                                     in_node_features, bias=bias)
+        self.linear = nn.Linear(in_node_features * 2, out_features, bias=bias)
+        self.in_edge_features = in_edge_features
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for lin in (self.linear, self.neigh_linear, self.edge_linear):
+            _xavier_relu_(lin)
+
+    def forward(self, features, edge_index, edge_features=None):
+        from .scatter import scatter
+        _lib.require_gpu(features)
+        h = self.neigh_linear(features)
+        if edge_features is None:
+            edge_features = torch.abs(h[edge_index[0]] - h[edge_index[1]])
+        new_h = self.edge_linear(torch.cat((h[edge_index[1]], edge_features), dim=-1))
+        s = scatter(new_h, edge_index[0], 0, out=h, reduce="mean")      # returns a new tensor: no clone needed
+        return self.linear(torch.cat([features, s], dim=-1))
+
+
+class HeteroRelEdgeConvLayer(_HeteroPerRelation):
+    """core/hgnn.py:66-95: one RelEdgeConv per relation, mean over the relations.  Node-level edge features [N, F_e] become
+    |f_i - f_j| per edge (:82-83), per-edge ones [E, F_e] are used as they are (:84-85), anything else is ignored (:86-87)."""
+
+    def __init__(self, in_features, out_features, etypes, bias=True, in_edge_features=None):
+        super().__init__()
+        self.out_features, self.in_features, self.etypes = out_features, in_features, etypes
+        self.reduction = "mean"
+        self.conv = nn.ModuleDict({k: RelEdgeConv(in_features, out_features, bias=bias, in_edge_features=in_edge_features)
+                                   for k in etypes.keys()})
+
+    def reset_parameters(self):
+        for c in self.conv.values():
+            c.reset_parameters()
+
+    def forward(self, x, edge_index, edge_type, edge_features=None):
+        if edge_features is not None and edge_features.shape[0] == x.shape[0]:
+            edge_features = torch.abs(edge_features[edge_index[0]] - edge_features[edge_index[1]])
+        elif edge_features is not None and edge_features.shape[0] == edge_index.shape[1]:
+            pass
+        else:
+            edge_features = None
         return self._run(x, edge_index, edge_type, edge_features)
 
 
@@ -508,21 +637,25 @@ class MetricalConvLayer(nn.Module):
 
 
 class MetricalGNN(nn.Module):
-    """In-tree MetricalGNN (core/hgnn.py:323-433), metrical=True/False, SAGE conv blocks, no JK / reledge
-    (the reference's own jk branch builds JumpingKnowledge(n_layers=hidden_features), :340)."""
+    """In-tree MetricalGNN (core/hgnn.py:323-433): metrical=True/False, any in-tree conv block (SageConvScatter,
+    ResGatedGraphConv, RelEdgeConv: models/chord.py:521-528), `use_reledge` (edge features into the first layer, :344-346,
+    :416-417) and `jk` (the reference builds JumpingKnowledge(n_layers=hidden_features), :340 — kept as it is)."""
 
     def __init__(self, input_features, hidden_features, output_features, etypes, num_layers=2, dropout=0.5,
                  use_reledge=False, jk=False, in_edge_features=None, metrical=False, conv_block=SageConvScatter):
         super().__init__()
-        if use_reledge or jk:
-            raise NotImplementedError("use_reledge / jk of the in-tree MetricalGNN are not on the HIP path")
         self.dropout, self.num_layers, self.num_hidden = dropout, num_layers, hidden_features
         self.use_metrical = metrical
+        self.use_reledge = use_reledge
+        self.use_knowledge = bool(jk)
         self.convs = nn.ModuleList()
         self.emb_beats = nn.Linear(input_features, hidden_features)
         self.emb_measures = nn.Linear(input_features, hidden_features)
         self.beat_convs, self.measure_convs, self.project_metrical = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
-        self.convs.append(HeteroConv(input_features, hidden_features, etypes=etypes, module=conv_block))
+        if jk:
+            self.jk = JumpingKnowledge(n_hidden=hidden_features, n_layers=hidden_features)
+        self.convs.append(HeteroConv(input_features, hidden_features, etypes=etypes,
+                                     in_edge_features=in_edge_features if use_reledge else None, module=conv_block))
         for _ in range(max(num_layers - 2, 0)):
             self.convs.append(HeteroConv(hidden_features, hidden_features, etypes=etypes, module=conv_block))
             if metrical:
@@ -549,11 +682,18 @@ class MetricalGNN(nn.Module):
             return F.normalize(F.relu(h), p=2.0, dim=-1), h_beat, h_measure
 
         h = x
+        hs = []
         for i in range(len(self.convs) - 1):
             if i != 0 and self.use_metrical:
                 h, h_beat, h_measure = metrical(i - 1, h, h_beat, h_measure)
-            h = self.convs[i](h, edge_index, edge_type)
+            if i == 0 and self.use_reledge:                                   # first layer only: :416-417
+                h = self.convs[i](h, edge_index, edge_type, edge_features=rel_edge)
+            else:
+                h = self.convs[i](h, edge_index, edge_type)
             h = F.dropout(F.relu(F.normalize(h, p=2.0, dim=-1)), p=self.dropout, training=self.training)
+            hs.append(h)
+        if self.use_knowledge:
+            h = self.jk(hs)
         if self.use_metrical:
             h, h_beat, h_measure = metrical(len(self.beat_convs) - 1, h, h_beat, h_measure)
         return self.convs[-1](h, edge_index, edge_type)

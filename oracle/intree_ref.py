@@ -230,3 +230,111 @@ def onset_pool(x: torch.Tensor, onset_edges: torch.Tensor, batch_size: int) -> t
     n = x.shape[0]
     pooled = (x + _segment_sum(x[e[1]], e[0], n)) / _degree(e[0], n, x.dtype).clamp(min=1).unsqueeze(-1)
     return torch.cat([x, pooled], dim=-1)
+
+
+# ------------------------------------------------------------------------------------------
+# core/gnn.py:99-106  RelEdgeConv.forward
+#   h = W_n x + b ; e_ij = |h_i - h_j| unless edge features are given ; m_ij = W_e [h_j || e_ij] + b_e
+#   s_i = (h_i + sum_{(i,j)} m_ij) / max(deg_i, 1)   [scatter onto edge row 0, out=h.clone(), mean]
+#   z = W [x || s] + b
+# ------------------------------------------------------------------------------------------
+def rel_edge_conv(P: Params, pre: str, x, ei, edge_features=None):
+    h = _lin(P, pre + "neigh_linear", x)
+    ef = (h[ei[0]] - h[ei[1]]).abs() if edge_features is None else edge_features
+    msg = _lin(P, pre + "edge_linear", torch.cat([h[ei[1]], ef], dim=-1))
+    n = x.shape[0]
+    s = (h + _segment_sum(msg, ei[0], n)) / _degree(ei[0], n, x.dtype).clamp(min=1).unsqueeze(-1)
+    return _lin(P, pre + "linear", torch.cat([x, s], dim=-1))
+
+
+# ------------------------------------------------------------------------------------------
+# core/hgnn.py:81-95  HeteroRelEdgeConvLayer.forward: node-level edge features [N, F_e] become |f_i - f_j| per edge
+# (:82-83), per-edge ones [E, F_e] are used as they are (:84-85), anything else is dropped (:86-87); mean over relations
+# ------------------------------------------------------------------------------------------
+def hetero_rel_edge_layer(P: Params, pre: str, rels: Sequence[str], x, ei, et, edge_features=None):
+    if edge_features is not None and edge_features.shape[0] == x.shape[0]:
+        edge_features = (edge_features[ei[0]] - edge_features[ei[1]]).abs()
+    elif edge_features is not None and edge_features.shape[0] == ei.shape[1]:
+        pass
+    else:
+        edge_features = None
+    outs = []
+    for code, rel in enumerate(rels):
+        m = et == code
+        outs.append(rel_edge_conv(P, f"{pre}conv.{rel}.", x, ei[:, m], edge_features[m] if edge_features is not None else None))
+    return torch.stack(outs, dim=0).mean(dim=0)
+
+
+# ------------------------------------------------------------------------------------------
+# core/hgnn.py:19-23  HeteroAttention.forward on the relation stack x [R, N, H] (the `lstm` reduction, :115, :41):
+# the bi-LSTM is batch_first, so it runs over the N NODES as the sequence with the R relations as the batch; the
+# softmax is over the last axis of [R, N] (the nodes); the result is the weighted sum over relations.
+# ------------------------------------------------------------------------------------------
+def hetero_attention(P: Params, pre: str, stack: torch.Tensor) -> torch.Tensor:
+    a = rnn_ref.lstm(P, pre + "lstm.", stack, num_layers=1, bidirectional=True)
+    a = _lin(P, pre + "att", a).squeeze(-1)
+    a = torch.softmax(a, dim=-1)
+    return (stack * a.unsqueeze(-1)).sum(dim=0)
+
+
+def hetero_layer_reduce(P: Params, pre: str, rels: Sequence[str], conv, x, ei, et, reduction: str):
+    """hetero_layer with the remaining reductions of core/hgnn.py:102-116 / :30-46 that can run at all: 'lstm'
+    (HeteroAttention) and 'none' ([R, N, H]).  'max' / 'min' return a (values, indices) pair whose `.to()` raises in
+    the reference and 'concat' calls torch.cat on a tensor (TypeError): nothing to restate for those."""
+    outs = [conv(P, f"{pre}conv.{rel}.", x, ei[:, et == code], None) for code, rel in enumerate(rels)]
+    stack = torch.stack(outs, dim=0)
+    if reduction == "lstm":
+        return hetero_attention(P, pre + "reduction.", stack)
+    if reduction == "none":
+        return stack
+    raise NotImplementedError(reduction)
+
+
+# ------------------------------------------------------------------------------------------
+# models/analysis.py:44-101  onsetwise_logit_aggregation (inference post-processing of the softmaxed predictions)
+# ------------------------------------------------------------------------------------------
+def onsetwise_logit_aggregation(probs: Dict[str, torch.Tensor], onset_edges: torch.Tensor, batch: torch.Tensor,
+                                onset_div: torch.Tensor, batch_size: Optional[int] = None, valid_label_mask=None,
+                                rna_keys=("quality", "inversion", "degree1", "degree2")) -> Dict[str, torch.Tensor]:
+    out = dict(probs)
+    if not (rna_keys and all(k in probs for k in rna_keys)):                                    # :45
+        return out
+    n_all = next(iter(probs.values())).shape[0]
+    batch_size = n_all if batch_size is None else batch_size                                   # :46
+    valid = torch.ones(batch_size, dtype=torch.bool) if valid_label_mask is None else valid_label_mask   # :48
+    e = onset_edges
+    e = e[:, (e[0] < batch_size) & (e[1] < batch_size)]                                        # :50-53
+    e = e[:, e[0] != e[1]]                                                                      # :55
+    tpc = None
+    if "tpc_in_label" in probs:                                                                 # :57-59
+        tpc = probs["tpc_in_label"].argmax(-1).bool()
+        e = e[:, tpc[e[0]] & tpc[e[1]]]
+    agg = {}
+    for k, v in probs.items():                                                                  # :64-66: scatter_mean(out=v).softmax
+        if k in rna_keys:
+            n = v.shape[0]
+            s = (v + _segment_sum(v[e[0]], e[1], n)) / _degree(e[1], n, v.dtype).clamp(min=1).unsqueeze(-1)
+            agg[k] = torch.softmax(s, dim=-1)
+    agg = {k: torch.softmax(v[valid], dim=-1) for k, v in agg.items()}                          # :68
+    out.update(agg)                                                                             # :69
+    bid = batch[:batch_size][valid]                                                             # :70
+    if bool(torch.all(bid == bid[0])):                                                          # :71
+        onsets = onset_div[:batch_size][valid]
+        onsets = onsets - onsets.min()
+        if tpc is not None:                                                                     # :74-76
+            onsets_f = onsets[tpc]
+            agg = {k: v[tpc] for k, v in agg.items()}
+        else:
+            onsets_f = onsets
+        uniq, inv = torch.unique(onsets_f, return_inverse=True)                                 # :79
+        first = torch.cat([torch.zeros(1, dtype=torch.long), (inv[1:] != inv[:-1]).nonzero(as_tuple=True)[0] + 1])   # :80-81
+        per_onset = {k: v[first] for k, v in agg.items()}                                       # :82
+        for k in rna_keys:                                                                      # :84-100
+            pred = per_onset[k].argmax(-1)
+            cp = torch.cat([torch.zeros(1, dtype=torch.long), (pred[1:] != pred[:-1]).nonzero(as_tuple=True)[0] + 1])
+            vals = uniq[cp]
+            rows = per_onset[k][cp]
+            for i in range(len(cp) - 1):                                                        # the last segment stays as it is
+                m = (vals[i] <= onsets) & (onsets < vals[i + 1])
+                out[k][m] = rows[i]
+    return out
