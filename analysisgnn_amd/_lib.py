@@ -34,6 +34,13 @@ class RowendItem(C.Structure):
 ROWEND_MAX_ITEMS = 64
 
 
+class ReltItem(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p), ("ld_x", C.c_int64), ("ld_y", C.c_int64)]
+
+
+RELT_MAX_ITEMS = 4
+
+
 class Rel(C.Structure):
     _fields_ = [("src", C.c_void_p), ("rowptr", C.c_void_p), ("rowend", C.c_void_p), ("col", C.c_void_p),
                 ("ew", C.c_void_p), ("colscale", C.c_void_p), ("ld_src", C.c_int64)]
@@ -86,6 +93,11 @@ SIGNATURES = {
     "agnn_hgt_attn_bwd_src_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
                                             C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "agnn_relt_fwd_f32": (C.c_int, [C.c_int, C.POINTER(ReltItem), C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
+    "agnn_relt_bwd_f32": (C.c_int, [C.c_int, C.POINTER(ReltItem), C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
+    "agnn_relt_dw_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int64]),
+    "agnn_relt_dw_f32": (C.c_int, [C.c_int, C.POINTER(ReltItem), C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_size_t,
+                                  C.c_void_p]),
     "agnn_gated_fwd_f32": (C.c_int, [C.POINTER(Gated), C.c_void_p, C.c_int64, C.c_void_p]),
     "agnn_gated_bwd_dst_f32": (C.c_int, [C.POINTER(Gated), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "agnn_gated_bwd_src_f32": (C.c_int, [C.POINTER(Gated), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -233,6 +233,69 @@ class _BlockDiagWeight(torch.autograd.Function):
         return gw, None, None, None, None
 
 
+RELT_D = 64           # the head width the relation-transform kernels are built for (csrc/relt.hip)
+RELT_ENABLED = True   # A/B switch: False = round 1's dense GEMM against a block-diagonal weight
+
+
+class _RelTransform(torch.autograd.Function):
+    """(k', v') for the relations `rel_ids` leaving one source type: k'[:, r*H + h*D + j] = sum_i k[:, h*D + i] *
+    k_rel.weight[rel_ids[r]*heads + h, i, j] (same for v) — `agnn_relt_*`: R*heads independent D x D products per operand on
+    the fp32 MFMA, K and V in one launch, instead of one dense [N, H] x [H, R*H] GEMM against a block-diagonal weight
+    (heads x the useful FLOPs) and the launches that assemble it."""
+
+    @staticmethod
+    def forward(ctx, k, v, wk, wv, rel_ids: tuple, heads: int, D: int):
+        dev = _lib.require_gpu(k, v, wk, wv)
+        lib = _lib.load()
+        k, v = _mat(k), _mat(v)
+        R, H, N = len(rel_ids), heads * D, k.shape[0]
+        sel = _index_tensor(tuple(r * heads + h for r in rel_ids for h in range(heads)), dev)
+        Wk = wk.detach().index_select(0, sel)                     # [R*heads, D, D], contiguous
+        Wv = wv.detach().index_select(0, sel)
+        yk = torch.empty((N, R * H), dtype=torch.float32, device=dev)
+        yv = torch.empty((N, R * H), dtype=torch.float32, device=dev)
+        items = (_lib.ReltItem * 2)()
+        for it, (x, w, y) in zip(items, ((k, Wk, yk), (v, Wv, yv))):
+            it.x, it.w, it.y, it.ld_x, it.ld_y = x.data_ptr(), w.data_ptr(), y.data_ptr(), x.stride(0), y.stride(0)
+        if N > 0:
+            _lib.check(lib.agnn_relt_fwd_f32(2, items, R, heads, D, N, _lib.stream_ptr(dev)), "agnn_relt_fwd_f32")
+        ctx.save_for_backward(k, v, Wk, Wv, sel)
+        ctx.meta = (R, heads, D, tuple(wk.shape), tuple(wv.shape))
+        return yk, yv
+
+    @staticmethod
+    def backward(ctx, dyk, dyv):
+        k, v, Wk, Wv, sel = ctx.saved_tensors
+        R, heads, D, wk_shape, wv_shape = ctx.meta
+        dev = k.device
+        lib = _lib.load()
+        N, H = k.shape[0], heads * D
+        zk = dyk is None
+        dyk = _mat(dyk) if dyk is not None else torch.zeros((N, R * H), dtype=torch.float32, device=dev)
+        dyv = _mat(dyv) if dyv is not None else torch.zeros((N, R * H), dtype=torch.float32, device=dev)
+        dk = dv = gwk = gwv = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dk = torch.empty((N, H), dtype=torch.float32, device=dev)
+            dv = torch.empty((N, H), dtype=torch.float32, device=dev)
+            Wkt, Wvt = Wk.transpose(1, 2).contiguous(), Wv.transpose(1, 2).contiguous()
+            items = (_lib.ReltItem * 2)()
+            for it, (x, w, y) in zip(items, ((dyk, Wkt, dk), (dyv, Wvt, dv))):
+                it.x, it.w, it.y, it.ld_x, it.ld_y = x.data_ptr(), w.data_ptr(), y.data_ptr(), x.stride(0), y.stride(0)
+            if N > 0:
+                _lib.check(lib.agnn_relt_bwd_f32(2, items, R, heads, D, N, _lib.stream_ptr(dev)), "agnn_relt_bwd_f32")
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            dWk, dWv = torch.empty_like(Wk), torch.empty_like(Wv)
+            nws = int(lib.agnn_relt_dw_workspace_bytes(2, R, heads, D, N))
+            ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=dev)
+            items = (_lib.ReltItem * 2)()
+            for it, (x, dy, y) in zip(items, ((k, dyk, dWk), (v, dyv, dWv))):
+                it.x, it.w, it.y, it.ld_x, it.ld_y = x.data_ptr(), dy.data_ptr(), y.data_ptr(), x.stride(0), dy.stride(0)
+            _lib.check(lib.agnn_relt_dw_f32(2, items, R, heads, D, N, ws.data_ptr(), nws, _lib.stream_ptr(dev)), "agnn_relt_dw_f32")
+            gwk = torch.zeros(wk_shape, dtype=torch.float32, device=dev).index_copy_(0, sel, dWk)
+            gwv = torch.zeros(wv_shape, dtype=torch.float32, device=dev).index_copy_(0, sel, dWv)
+        return dk, dv, gwk, gwv, None, None, None
+
+
 def _arange(n: int, device) -> torch.Tensor:
     return _index_tensor(tuple(range(n)), device)
 
@@ -288,10 +351,14 @@ class HGTConv(nn.Module):
             for e_idx in used:
                 by_src.setdefault(self.edge_types[e_idx][0], []).append(e_idx)
             for s_t, e_ids in by_src.items():
-                Wk_s = block_diag_weight(self.k_rel.weight, tuple(e_ids), len(self.edge_types), heads, D)     # [R_s*H, H]
-                Wv_s = block_diag_weight(self.v_rel.weight, tuple(e_ids), len(self.edge_types), heads, D)
-                ks = col_split(linear(k[s_t], Wk_s), len(e_ids))
-                vs = col_split(linear(v[s_t], Wv_s), len(e_ids))
+                if RELT_ENABLED and D == RELT_D and k[s_t].is_cuda:
+                    kp, vp = _RelTransform.apply(k[s_t], v[s_t], self.k_rel.weight, self.v_rel.weight, tuple(e_ids), heads, D)
+                    ks, vs = col_split(kp, len(e_ids)), col_split(vp, len(e_ids))
+                else:
+                    Wk_s = block_diag_weight(self.k_rel.weight, tuple(e_ids), len(self.edge_types), heads, D)     # [R_s*H, H]
+                    Wv_s = block_diag_weight(self.v_rel.weight, tuple(e_ids), len(self.edge_types), heads, D)
+                    ks = col_split(linear(k[s_t], Wk_s), len(e_ids))
+                    vs = col_split(linear(v[s_t], Wv_s), len(e_ids))
                 for j, e_idx in enumerate(e_ids):
                     kv_of[e_idx] = (ks[j], vs[j])
         out = {}

@@ -24,6 +24,7 @@
  *   agnn_gproj_*          the task heads' last Linear layers as one grouped projection (ref: models/analysis.py:486-496)
  *   agnn_adamw_f32        gradient clipping + `torch.optim.AdamW` step on the flat buffers (ref: models/analysis.py:1380-1381)
  *   agnn_multitask_ce_f32 the 21 per-task CrossEntropyLoss terms (ref: models/analysis.py:881-888)
+ *   agnn_relt_*           PyG `HGTConv` per-head relation transforms (k_rel / v_rel)
  *   agnn_hgt_attn_*       PyG `HGTConv` message/softmax/aggregate, reached through graphmuse
  *                         `HybridHGT` (ref: models/analysis.py:445-453)
  *
@@ -395,6 +396,35 @@ int agnn_train_loss_bwd_f32(const float* dlogits, int64_t ld, const int32_t* seg
                             int32_t n_cols, const float* inv_count, const float* g, float* out, int64_t ld_out,
                             const float* feat, int64_t ld_feat, int32_t feat_cols, float lambda_feat, float* dfeat,
                             int64_t ld_dfeat, agnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-head relation transforms of HGTConv (PyG `k_rel` / `v_rel`: one D x D matrix per (edge type, head); reached through
+ * graphmuse's HybridHGT, ref models/analysis.py:445-453 `heads=4`).  For the n_rel relations leaving one node type:
+ *     forward   y[n, (r*heads + h)*D + j] = sum_i x[n, h*D + i] * w[((r*heads + h)*D + i)*D + j]
+ *     backward  dx[n, h*D + i]            = sum_r sum_j dy[n, (r*heads + h)*D + j] * wt[((r*heads + h)*D + j)*D + i]
+ *     dw        dw[((r*heads + h)*D + i)*D + j] = sum_n x[n, h*D + i] * dy[n, (r*heads + h)*D + j]
+ * i.e. n_rel*heads independent [n, D] x [D, D] products on the fp32-input MFMA instead of one dense GEMM against a
+ * block-diagonal weight (heads x the useful FLOPs).  D = 64.  Up to AGNN_RELT_MAX_ITEMS operands of the same shape
+ * (K and V) per launch.  Item fields per entry point:
+ *     fwd: x = x [n, heads*D] (ld_x), w = blocks [n_rel*heads][D][D], y = y [n, n_rel*heads*D] (ld_y)
+ *     bwd: x = dy (ld_x), w = the TRANSPOSED blocks, y = dx [n, heads*D] (ld_y)
+ *     dw:  x = x (ld_x), w = dy (ld_y), y = dw blocks [n_rel*heads][D][D] (contiguous); row slices are summed in a
+ *          fixed order through `workspace` (agnn_relt_dw_workspace_bytes).
+ * ------------------------------------------------------------------------------------------ */
+#define AGNN_RELT_MAX_ITEMS 4
+typedef struct {
+  const float* x;
+  const float* w;
+  float* y;
+  int64_t ld_x, ld_y;
+} agnn_relt_item_t;
+int agnn_relt_fwd_f32(int n_items, const agnn_relt_item_t* items /* (host) */, int32_t n_rel, int32_t heads, int32_t D,
+                      int64_t n_rows, agnn_stream_t stream);
+int agnn_relt_bwd_f32(int n_items, const agnn_relt_item_t* items /* (host) */, int32_t n_rel, int32_t heads, int32_t D,
+                      int64_t n_rows, agnn_stream_t stream);
+size_t agnn_relt_dw_workspace_bytes(int n_items, int32_t n_rel, int32_t heads, int32_t D, int64_t n_rows);
+int agnn_relt_dw_f32(int n_items, const agnn_relt_item_t* items /* (host) */, int32_t n_rel, int32_t heads, int32_t D,
+                     int64_t n_rows, void* workspace, size_t workspace_bytes, agnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Global-norm gradient clipping + AdamW over flat fp32 buffers (ref optimizer: models/analysis.py:1380-1381

@@ -166,3 +166,37 @@ def test_analysis_model_hgt_logits():
                 I["batch_size"], None, None)
     for t in tasks:
         assert_close(out[t], ref[t], TOL, f"logits[{t}]")
+
+
+@pytest.mark.parametrize("N,R,heads,T", [(16000, 6, 4, 6), (1003, 2, 4, 7), (130, 1, 1, 3), (5, 3, 2, 3)])
+def test_relation_transform_kernels_match_float64(N, R, heads, T):
+    """agnn_relt_fwd / _bwd / _dw (the per-head D x D relation transforms of HGTConv, D = 64) against per-block float64
+    matmuls: K and V in one launch, relations picked out of a larger parameter (`rel_ids`), rows not a multiple of the
+    128-row tile, gradients w.r.t. both operands and both parameters."""
+    from analysisgnn_amd.hgt import _RelTransform
+    D, H = 64, heads * 64
+    g = torch.Generator().manual_seed(N + R)
+    rel_ids = tuple(sorted(torch.randperm(T, generator=g)[:R].tolist()))
+    kqv = torch.randn(N, 3 * H, generator=g)                       # K | Q | V side by side: the operands are column views
+    wk = torch.randn(T * heads, D, D, generator=g) * 0.2
+    wv = torch.randn(T * heads, D, D, generator=g) * 0.2
+    gk, gv = torch.randn(N, R * H, generator=g), torch.randn(N, R * H, generator=g)
+    kqv64, wk64, wv64 = (t.double().requires_grad_(True) for t in (kqv, wk, wv))
+
+    def ref_of(x, w):
+        blocks = []
+        for r in rel_ids:
+            for h in range(heads):
+                blocks.append(x[:, h * D:(h + 1) * D] @ w[r * heads + h])
+        return torch.cat(blocks, dim=1)
+    rk, rv = ref_of(kqv64[:, :H], wk64), ref_of(kqv64[:, 2 * H:], wv64)
+    ((rk * gk.double()).sum() + (rv * gv.double()).sum()).backward()
+    kd = kqv.to(DEV).requires_grad_(True)
+    wkd, wvd = wk.to(DEV).requires_grad_(True), wv.to(DEV).requires_grad_(True)
+    yk, yv = _RelTransform.apply(kd[:, :H], kd[:, 2 * H:], wkd, wvd, rel_ids, heads, D)
+    ((yk * gk.to(DEV)).sum() + (yv * gv.to(DEV)).sum()).backward()
+    assert_close(yk, rk.float(), 1e-5, "k'")
+    assert_close(yv, rv.float(), 1e-5, "v'")
+    assert_close(kd.grad, kqv64.grad.float(), 1e-5, "d kqv")
+    assert_close(wkd.grad, wk64.grad.float(), 1e-5, "d k_rel.weight")
+    assert_close(wvd.grad, wv64.grad.float(), 1e-5, "d v_rel.weight")
