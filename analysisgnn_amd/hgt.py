@@ -17,7 +17,7 @@ from . import _lib
 from .encoders import TrimPlan, _HybridMixin
 from .graph import Csr, HeteroIndex, hetero_index
 from .linear import linear
-from .params import pack
+from .params import cat_rows, pack
 
 EdgeType = Tuple[str, str, str]
 
@@ -235,6 +235,7 @@ class _BlockDiagWeight(torch.autograd.Function):
 
 RELT_D = 64           # the head width the relation-transform kernels are built for (csrc/relt.hip)
 RELT_ENABLED = True   # A/B switch: False = round 1's dense GEMM against a block-diagonal weight
+CORE_ENABLED = True   # A/B switch: False = one autograd node per relation / destination type (round 1's graph)
 
 
 class _RelTransform(torch.autograd.Function):
@@ -296,6 +297,215 @@ class _RelTransform(torch.autograd.Function):
         return dk, dv, gwk, gwv, None, None, None
 
 
+class _CorePlan:
+    """Static layout of one HGTConv layer on one batch (nothing that carries a gradient)."""
+
+    def __init__(self, types, n_of, heads, D, src_rels, dst_rels, block_of, index, e_keep, n_edge_types):
+        self.types, self.n_of, self.heads, self.D = types, n_of, heads, D
+        self.src_rels, self.dst_rels, self.block_of = src_rels, dst_rels, block_of
+        self.index, self.e_keep, self.n_edge_types = index, e_keep, n_edge_types
+
+    def limit(self, et):
+        return None if self.e_keep is None else self.e_keep[et]
+
+
+class _HGTCore(torch.autograd.Function):
+    """Everything of an HGTConv layer between the K|Q|V projections and the output projections, for ALL node types at
+    once:  kqv[t] [n_t, 3H]  ->  m[t] [n_t, H]  (relation transforms, scores, edge softmax over all incoming relations,
+    weighted sum).  One autograd node instead of ~15 per layer, so that every gradient is WRITTEN IN PLACE by a kernel:
+      * the attention's source-side pass writes dK' / dV' of a relation straight into its column block of the source type's
+        [N_s, R_s*H] gradient (no per-relation tensors, no packing launch, no zero-filled placeholders);
+      * the input-gradient relation transform writes dk / dv, and the destination-side pass writes dq, straight into the
+        three column blocks of d kqv[t] (no [N, 3H] re-assembly);
+      * the 1/sqrt(D) scale of p_rel, the per-relation stacking and the gradient fan-out are one small launch each way."""
+
+    @staticmethod
+    def forward(ctx, plan: _CorePlan, wk, wv, p_all, *kqv):
+        dev = _lib.require_gpu(wk, wv, p_all, *kqv)
+        lib = _lib.load()
+        heads, D = plan.heads, plan.D
+        H = heads * D
+        X = {t: _mat(x) for t, x in zip(plan.types, kqv)}
+        for t, x in X.items():
+            if x.shape[1] != 3 * H:
+                raise _lib.AgnnError("HGT core: kqv must be [n, 3H]")
+        # relation transforms, K and V of one source type in one launch
+        kp, vp, Wk, Wv = {}, {}, {}, {}
+        for s_t, e_ids in plan.src_rels.items():
+            x = X[s_t]
+            N, R = x.shape[0], len(e_ids)
+            sel = _index_tensor(tuple(e * heads + h for e in e_ids for h in range(heads)), dev)
+            Wk[s_t], Wv[s_t] = wk.detach().index_select(0, sel), wv.detach().index_select(0, sel)
+            kp[s_t] = torch.empty((N, R * H), dtype=torch.float32, device=dev)
+            vp[s_t] = torch.empty((N, R * H), dtype=torch.float32, device=dev)
+            if N > 0:
+                items = (_lib.ReltItem * 2)()
+                for it, (off, w, y) in zip(items, ((0, Wk[s_t], kp[s_t]), (2 * H, Wv[s_t], vp[s_t]))):
+                    it.x, it.w, it.y, it.ld_x, it.ld_y = x.data_ptr() + 4 * off, w.data_ptr(), y.data_ptr(), x.stride(0), y.stride(0)
+                _lib.check(lib.agnn_relt_fwd_f32(2, items, R, heads, D, N, _lib.stream_ptr(dev)), "agnn_relt_fwd_f32")
+        ps = (p_all.detach() * (1.0 / math.sqrt(D))).contiguous()                   # [n_edge_types, heads]
+        outs, stats = [], {}
+        for t in plan.types:
+            n = plan.n_of[t]
+            rels = plan.dst_rels.get(t, [])
+            if not rels or n == 0:
+                outs.append(torch.zeros((n, H), dtype=torch.float32, device=dev))
+                continue
+            out = torch.empty((n, H), dtype=torch.float32, device=dev)
+            m = torch.empty((n, heads), dtype=torch.float32, device=dev)
+            linv = torch.empty((n, heads), dtype=torch.float32, device=dev)
+            arr, keep = _HGTCore._rel_table(plan, rels, kp, vp, ps, H)
+            q = X[t]
+            _lib.check(lib.agnn_hgt_attn_fwd_f32(len(rels), arr, q.data_ptr() + 4 * H, q.stride(0), n, H, heads, out.data_ptr(),
+                                                 out.stride(0), m.data_ptr(), linv.data_ptr(), _lib.stream_ptr(dev)), "agnn_hgt_attn_fwd_f32")
+            stats[t] = (m, linv)
+            outs.append(out)
+        ctx.plan = plan
+        ctx.srcs = list(plan.src_rels.keys())
+        ctx.dsts = list(stats.keys())
+        saved = list(X.values()) + [ps]
+        for s_t in ctx.srcs:
+            saved += [Wk[s_t], Wv[s_t], kp[s_t], vp[s_t]]
+        for t in ctx.dsts:
+            saved += [stats[t][0], stats[t][1], outs[plan.types.index(t)]]
+        ctx.save_for_backward(*saved)
+        ctx.shapes = (tuple(wk.shape), tuple(wv.shape), tuple(p_all.shape))
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def _rel_table(plan, rels, kp, vp, ps, H, extra=None):
+        arr = (_lib.HgtRel * max(len(rels), 1))()
+        keep = []
+        for r, (e_idx, et) in enumerate(rels):
+            s_t, blk = plan.block_of[e_idx]
+            c = plan.index.fwd[et]
+            re = c.rowend(plan.limit(et))
+            keep.append(re)
+            arr[r].k, arr[r].v = kp[s_t].data_ptr() + 4 * blk * H, vp[s_t].data_ptr() + 4 * blk * H
+            arr[r].ld = kp[s_t].stride(0)
+            arr[r].rowptr, arr[r].rowend = c.rowptr.data_ptr(), _lib.ptr(re)
+            arr[r].col, arr[r].perm = c.col.data_ptr(), c.perm.data_ptr()
+            arr[r].pscale = ps[e_idx].data_ptr()
+            if extra is not None:
+                arr[r].alpha, arr[r].gs, arr[r].tdot = (x.data_ptr() for x in extra[r])
+        return arr, keep
+
+    @staticmethod
+    def backward(ctx, *dms):
+        plan: _CorePlan = ctx.plan
+        lib = _lib.load()
+        heads, D = plan.heads, plan.D
+        H = heads * D
+        saved = list(ctx.saved_tensors)
+        nt = len(plan.types)
+        X = dict(zip(plan.types, saved[:nt]))
+        ps = saved[nt]
+        pos = nt + 1
+        Wk, Wv, kp, vp = {}, {}, {}, {}
+        for s_t in ctx.srcs:
+            Wk[s_t], Wv[s_t], kp[s_t], vp[s_t] = saved[pos:pos + 4]
+            pos += 4
+        stats = {}
+        for t in ctx.dsts:
+            stats[t] = tuple(saved[pos:pos + 3])
+            pos += 3
+        dev = ps.device
+        st = _lib.stream_ptr(dev)
+        dkqv = {t: torch.empty_like(X[t]) for t in plan.types}
+        dkp = {s_t: torch.empty_like(kp[s_t]) for s_t in ctx.srcs}
+        dvp = {s_t: torch.empty_like(vp[s_t]) for s_t in ctx.srcs}
+        written = set()                                              # relations whose dK' / dV' block a kernel has written
+        zero_q = set()                                               # types whose dq is structurally zero
+        dps_rows, dps_ids = [], []
+        for ti, t in enumerate(plan.types):
+            dm = dms[ti]
+            n = plan.n_of[t]
+            rels = plan.dst_rels.get(t, [])
+            if t not in stats or dm is None:                         # no incoming relation / output not used downstream: dq = 0
+                zero_q.add(t)
+                continue
+            dm = _mat(dm)
+            m, linv, out = stats[t]
+            q = X[t]
+            R = len(rels)
+            ne = [max(plan.index.num_edges[et], 1) for _, et in rels]
+            offs = [0]
+            for k_ in ne:
+                offs.append(offs[-1] + k_)
+            a_all = torch.empty((offs[-1], heads), dtype=torch.float32, device=dev)
+            g_all = torch.empty((offs[-1], heads), dtype=torch.float32, device=dev)
+            # tdot as [R, max E_r, heads] (zero padded): the per-relation sums over edges are ONE reduction instead of R
+            t3 = torch.zeros((R, max(ne), heads), dtype=torch.float32, device=dev)
+            extra = [(a_all[offs[r]:offs[r + 1]], g_all[offs[r]:offs[r + 1]], t3[r, :ne[r]]) for r in range(R)]
+            arr, keep = _HGTCore._rel_table(plan, rels, kp, vp, ps, H, extra)
+            dq_ptr = dkqv[t].data_ptr() + 4 * H
+            _lib.check(lib.agnn_hgt_attn_bwd_dst_f32(R, arr, q.data_ptr() + 4 * H, q.stride(0), dm.data_ptr(), dm.stride(0), out.data_ptr(),
+                                                     out.stride(0), m.data_ptr(), linv.data_ptr(), n, H, heads, dq_ptr, dkqv[t].stride(0), st),
+                       "agnn_hgt_attn_bwd_dst_f32")
+            dps_rows.append(t3.sum(dim=1))
+            dps_ids += [e_idx for e_idx, _ in rels]
+            for r, (e_idx, et) in enumerate(rels):
+                s_t, blk = plan.block_of[e_idx]
+                c = plan.index.bwd[et]
+                n_src = X[s_t].shape[0]
+                re = c.rowend(plan.limit(et))
+                lim = n if plan.index.fwd[et].n_rows > n else _lib.INT32_MAX
+                if n_src > 0:
+                    _lib.check(lib.agnn_hgt_attn_bwd_src_f32(c.rowptr.data_ptr(), _lib.ptr(re), c.col.data_ptr(), c.perm.data_ptr(),
+                                                             extra[r][0].data_ptr(), extra[r][1].data_ptr(), q.data_ptr() + 4 * H, q.stride(0),
+                                                             dm.data_ptr(), dm.stride(0), n_src, lim, H, heads,
+                                                             dkp[s_t].data_ptr() + 4 * blk * H, dvp[s_t].data_ptr() + 4 * blk * H,
+                                                             dkp[s_t].stride(0), st), "agnn_hgt_attn_bwd_src_f32")
+                written.add(e_idx)
+        gwk = gwv = None
+        wk_shape, wv_shape, p_shape = ctx.shapes
+        dead = set()                                                 # types whose whole d kqv is structurally zero: hand back None,
+        for s_t in plan.types:                                       # so that autograd prunes everything upstream of it
+            x = X[s_t]
+            N = x.shape[0]
+            live_src = s_t in kp and any(e_idx in written for e_idx in plan.src_rels[s_t])
+            if not live_src:
+                if s_t in zero_q:
+                    dead.add(s_t)
+                else:
+                    dkqv[s_t][:, :H].zero_()                         # no (live) outgoing relation: dk = dv = 0
+                    dkqv[s_t][:, 2 * H:].zero_()
+                continue
+            if s_t in zero_q:
+                dkqv[s_t][:, H:2 * H].zero_()
+            e_ids = plan.src_rels[s_t]
+            R = len(e_ids)
+            for blk, e_idx in enumerate(e_ids):
+                if e_idx not in written:
+                    dkp[s_t][:, blk * H:(blk + 1) * H].zero_()
+                    dvp[s_t][:, blk * H:(blk + 1) * H].zero_()
+            dx = dkqv[s_t]
+            if N > 0:
+                Wkt, Wvt = Wk[s_t].transpose(1, 2).contiguous(), Wv[s_t].transpose(1, 2).contiguous()
+                items = (_lib.ReltItem * 2)()
+                for it, (dy, w, off) in zip(items, ((dkp[s_t], Wkt, 0), (dvp[s_t], Wvt, 2 * H))):
+                    it.x, it.w, it.y, it.ld_x, it.ld_y = dy.data_ptr(), w.data_ptr(), dx.data_ptr() + 4 * off, dy.stride(0), dx.stride(0)
+                _lib.check(lib.agnn_relt_bwd_f32(2, items, R, heads, D, N, st), "agnn_relt_bwd_f32")
+            dWk, dWv = torch.empty_like(Wk[s_t]), torch.empty_like(Wv[s_t])
+            nws = int(lib.agnn_relt_dw_workspace_bytes(2, R, heads, D, N))
+            ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=dev)
+            items = (_lib.ReltItem * 2)()
+            for it, (off, dy, y) in zip(items, ((0, dkp[s_t], dWk), (2 * H, dvp[s_t], dWv))):
+                it.x, it.w, it.y, it.ld_x, it.ld_y = x.data_ptr() + 4 * off, dy.data_ptr(), y.data_ptr(), x.stride(0), dy.stride(0)
+            _lib.check(lib.agnn_relt_dw_f32(2, items, R, heads, D, N, ws.data_ptr(), nws, st), "agnn_relt_dw_f32")
+            sel = _index_tensor(tuple(e * heads + h for e in e_ids for h in range(heads)), dev)
+            if gwk is None:
+                gwk = torch.zeros(wk_shape, dtype=torch.float32, device=dev)
+                gwv = torch.zeros(wv_shape, dtype=torch.float32, device=dev)
+            gwk.index_copy_(0, sel, dWk)
+            gwv.index_copy_(0, sel, dWv)
+        dp_all = torch.zeros(p_shape, dtype=torch.float32, device=dev)
+        if dps_rows:
+            dp_all.index_copy_(0, _index_tensor(tuple(dps_ids), dev), torch.cat(dps_rows, dim=0) * (1.0 / math.sqrt(D)))
+        return (None, gwk, gwv, dp_all, *[None if t in dead else dkqv[t] for t in plan.types])
+
+
 def _arange(n: int, device) -> torch.Tensor:
     return _index_tensor(tuple(range(n)), device)
 
@@ -328,6 +538,8 @@ class HGTConv(nn.Module):
         heads, H = self.heads, self.out_channels
         D = H // heads
         n_of = {t: (n_keep[t] if n_keep is not None else int(x.shape[0])) for t, x in x_dict.items()}
+        if CORE_ENABLED and RELT_ENABLED and D == RELT_D and all(x.shape[1] == self.in_channels for x in x_dict.values()):
+            return self._forward_core(x_dict, index, n_of, e_keep)
         # k | q | v in ONE projection per node type; the three H-wide column blocks are handed out as views (col_split)
         k, q, v = {}, {}, {}
         for t, x in x_dict.items():
@@ -381,6 +593,43 @@ class HGTConv(nn.Module):
             if o.shape[-1] == x.shape[-1]:
                 beta = torch.sigmoid(self.skip[t])
                 o = torch.lerp(x if n >= x.shape[0] else x[:n], o, beta)          # beta * o + (1 - beta) * x in one launch
+            out[t] = o
+        return out
+
+
+    def adjacent_parameter_groups(self):
+        """The per-relation priors are consumed stacked (one [n_edge_types, heads] operand): adjacent in the flat buffer
+        (dp.plan_parameters) the stack is a view."""
+        return [[self.p_rel["__".join(e)] for e in self.edge_types]]
+
+    def _forward_core(self, x_dict, index: HeteroIndex, n_of, e_keep):
+        """One K|Q|V GEMM per node type -> `_HGTCore` (one autograd node for the whole message passing) -> one output GEMM
+        per node type (+ skip)."""
+        heads, H = self.heads, self.out_channels
+        D = H // heads
+        types = list(x_dict.keys())
+        kqv = []
+        for t in types:
+            lin = self.kqv_lin.lins[t]
+            x = x_dict[t]
+            kqv.append(linear(x if n_of[t] >= x.shape[0] else x[:n_of[t]], lin.weight, lin.bias))
+        src_rels: Dict[str, List[int]] = {}
+        dst_rels: Dict[str, List[Tuple[int, EdgeType]]] = {}
+        for e_idx, et in enumerate(self.edge_types):
+            s_t, _, d_t = et
+            if et in index.fwd and s_t in x_dict and d_t in x_dict:
+                src_rels.setdefault(s_t, []).append(e_idx)
+                dst_rels.setdefault(d_t, []).append((e_idx, et))
+        block_of = {e_idx: (s_t, blk) for s_t, ids in src_rels.items() for blk, e_idx in enumerate(ids)}
+        plan = _CorePlan(types, n_of, heads, D, src_rels, dst_rels, block_of, index, e_keep, len(self.edge_types))
+        p_all = cat_rows([self.p_rel["__".join(e)] for e in self.edge_types])       # [n_edge_types, heads]
+        ms = _HGTCore.apply(plan, self.k_rel.weight, self.v_rel.weight, p_all, *kqv)
+        out = {}
+        for t, m in zip(types, ms):
+            x, n = x_dict[t], n_of[t]
+            o = self.out_lin.lins[t](F.gelu(m))
+            if o.shape[-1] == x.shape[-1]:
+                o = torch.lerp(x if n >= x.shape[0] else x[:n], o, torch.sigmoid(self.skip[t]))
             out[t] = o
         return out
 

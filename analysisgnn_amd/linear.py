@@ -136,6 +136,7 @@ class _LinearFn(torch.autograd.Function):
         ctx.has_bias = b is not None
         ctx.wg_async = _async_ok(w) and _async_ok(b)
         ctx.b_ref = b if (b is not None and b.is_leaf) else None
+        ctx.set_materialize_grads(False)          # an undefined output gradient (a structurally dead branch) stays undefined upstream
         if acc is not None:                       # y = acc + x W^T (+ b): the GEMM's beta = 1 epilogue, no separate add
             y = torch.addmm(acc, x, w.t())
             return y + b if b is not None else y
@@ -143,6 +144,8 @@ class _LinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return None, None, None, None
         x, w = ctx.saved_tensors
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
