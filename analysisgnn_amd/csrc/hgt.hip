@@ -32,11 +32,18 @@ __device__ __forceinline__ float4 f4z() { return make_float4(0.f, 0.f, 0.f, 0.f)
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
   return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
 }
-// sum over the gl (power of two <= 64) adjacent lanes that hold one head; every lane gets the total
+// sum over the gl (power of two <= 64) adjacent lanes that hold one head; every lane gets the total.  Up to 16 lanes
+// (D <= 64: a head sits inside one 16-lane DPP row) the butterfly runs on the DPP cross-lane paths — quad_perm [1,0,3,2],
+// quad_perm [2,3,0,1], row_half_mirror, row_mirror — instead of ds_bpermute round trips through the LDS crossbar.
 __device__ __forceinline__ float group_sum(float v, int gl) {
-  for (int off = 1; off < gl; off <<= 1) v += __shfl_xor(v, off, 64);
+  if (gl >= 2) v += agnn::dpp_mov<0xB1>(v);
+  if (gl >= 4) v += agnn::dpp_mov<0x4E>(v);
+  if (gl >= 8) v += agnn::dpp_mov<0x141>(v);
+  if (gl >= 16) v += agnn::dpp_mov<0x140>(v);
+  for (int off = 16; off < gl; off <<= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+typedef const __attribute__((address_space(4))) int32_t* hk_i32p;      // wave-uniform index loads on the scalar unit
 
 struct HgtArgs {
   const float* q;
@@ -72,35 +79,51 @@ __global__ __launch_bounds__(256) void k_hgt_fwd(HgtTable t, HgtArgs a, float* _
     m[c] = -INFINITY;
     l[c] = 0.f;
   }
+  // Index phase on the scalar unit (rowptr / rowend of a relation are wave-uniform), the column ids of a segment in ONE
+  // vector register (broadcast with v_readlane), and TWO neighbours in flight: their four K' / V' rows are requested
+  // before the first score is reduced, and one running-max update (three exponentials) covers both.
   for (int r = 0; r < t.n_rel; ++r) {
     const agnn_hgt_rel_t& R = t.r[r];
-    const int start = R.rowptr[row];
-    const int end = (R.rowend != nullptr) ? R.rowend[row] : R.rowptr[row + 1];
+    const int start = ((hk_i32p)R.rowptr)[row];
+    const int end = (R.rowend != nullptr) ? ((hk_i32p)R.rowend)[row] : ((hk_i32p)R.rowptr)[row + 1];
+    const int n = end - start;
+    if (n <= 0) continue;
     float ps[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) ps[c] = R.pscale[head[c]];
-    for (int p = start; p < end; ++p) {
-      const int j = __builtin_amdgcn_readfirstlane(R.col[p]);
-      const float4* kp = reinterpret_cast<const float4*>(R.k + static_cast<int64_t>(j) * R.ld);
-      const float4* vp = reinterpret_cast<const float4*>(R.v + static_cast<int64_t>(j) * R.ld);
-      float4 kv[CH], vv[CH];
+    for (int base = 0; base < n; base += 64) {
+      const int mcnt = (n - base) < 64 ? (n - base) : 64;
+      const int cv = lane < mcnt ? R.col[start + base + lane] : 0;
+      for (int k = 0; k < mcnt; k += 2) {
+        const bool two = k + 1 < mcnt;
+        const int j0 = __builtin_amdgcn_readlane(cv, k);
+        const int j1 = __builtin_amdgcn_readlane(cv, two ? k + 1 : k);
+        const float4* kp0 = reinterpret_cast<const float4*>(R.k + static_cast<int64_t>(j0) * R.ld);
+        const float4* vp0 = reinterpret_cast<const float4*>(R.v + static_cast<int64_t>(j0) * R.ld);
+        const float4* kp1 = reinterpret_cast<const float4*>(R.k + static_cast<int64_t>(j1) * R.ld);
+        const float4* vp1 = reinterpret_cast<const float4*>(R.v + static_cast<int64_t>(j1) * R.ld);
+        float4 k0[CH], v0[CH], k1[CH], v1[CH];
 #pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        kv[c] = on[c] ? kp[c * 64 + lane] : f4z();
-        vv[c] = on[c] ? vp[c * 64 + lane] : f4z();
-      }
+        for (int c = 0; c < CH; ++c) {
+          k0[c] = on[c] ? kp0[c * 64 + lane] : f4z();
+          k1[c] = on[c] ? kp1[c * 64 + lane] : f4z();
+          v0[c] = on[c] ? vp0[c * 64 + lane] : f4z();
+          v1[c] = on[c] ? vp1[c * 64 + lane] : f4z();
+        }
 #pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        const float s = group_sum(dot4(qv[c], kv[c]), gl) * ps[c];
-        const float mn = fmaxf(m[c], s);
-        const float corr = expf(m[c] - mn);       // exp(-inf) = 0 on the first edge
-        const float pe = expf(s - mn);
-        l[c] = l[c] * corr + pe;
-        acc[c].x = acc[c].x * corr + pe * vv[c].x;
-        acc[c].y = acc[c].y * corr + pe * vv[c].y;
-        acc[c].z = acc[c].z * corr + pe * vv[c].z;
-        acc[c].w = acc[c].w * corr + pe * vv[c].w;
-        m[c] = mn;
+        for (int c = 0; c < CH; ++c) {
+          const float s0 = group_sum(dot4(qv[c], k0[c]), gl) * ps[c];
+          const float s1 = two ? group_sum(dot4(qv[c], k1[c]), gl) * ps[c] : -INFINITY;
+          const float mn = fmaxf(m[c], fmaxf(s0, s1));
+          const float corr = __expf(m[c] - mn);     // exp(-inf) = 0 on the first edge
+          const float p0 = __expf(s0 - mn), p1 = __expf(s1 - mn);
+          l[c] = fmaf(l[c], corr, p0 + p1);
+          acc[c].x = fmaf(acc[c].x, corr, fmaf(p0, v0[c].x, p1 * v1[c].x));
+          acc[c].y = fmaf(acc[c].y, corr, fmaf(p0, v0[c].y, p1 * v1[c].y));
+          acc[c].z = fmaf(acc[c].z, corr, fmaf(p0, v0[c].z, p1 * v1[c].z));
+          acc[c].w = fmaf(acc[c].w, corr, fmaf(p0, v0[c].w, p1 * v1[c].w));
+          m[c] = mn;
+        }
       }
     }
   }
@@ -154,35 +177,60 @@ __global__ __launch_bounds__(256) void k_hgt_bwd_dst(HgtTable t, HgtArgs a, cons
     linv[c] = linv_in[static_cast<int64_t>(row) * a.heads + head[c]];
     dqa[c] = f4z();
   }
+  // same loop structure as the forward pass: scalar index phase, column ids / COO positions of a segment in one vector
+  // register each, two neighbours' K' / V' rows in flight
   for (int r = 0; r < t.n_rel; ++r) {
     const agnn_hgt_rel_t& R = t.r[r];
-    const int start = R.rowptr[row];
-    const int end = (R.rowend != nullptr) ? R.rowend[row] : R.rowptr[row + 1];
+    const int start = ((hk_i32p)R.rowptr)[row];
+    const int end = (R.rowend != nullptr) ? ((hk_i32p)R.rowend)[row] : ((hk_i32p)R.rowptr)[row + 1];
+    const int n = end - start;
+    if (n <= 0) continue;
     float ps[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) ps[c] = R.pscale[head[c]];
-    for (int p = start; p < end; ++p) {
-      const int j = __builtin_amdgcn_readfirstlane(R.col[p]);
-      const int64_t e = __builtin_amdgcn_readfirstlane(R.perm[p]);
-      const float4* kp = reinterpret_cast<const float4*>(R.k + static_cast<int64_t>(j) * R.ld);
-      const float4* vp = reinterpret_cast<const float4*>(R.v + static_cast<int64_t>(j) * R.ld);
+    for (int base = 0; base < n; base += 64) {
+      const int mcnt = (n - base) < 64 ? (n - base) : 64;
+      const int cv = lane < mcnt ? R.col[start + base + lane] : 0;
+      const int pv = lane < mcnt ? R.perm[start + base + lane] : 0;
+      for (int k = 0; k < mcnt; k += 2) {
+        const bool two = k + 1 < mcnt;
+        const int k1i = two ? k + 1 : k;
+        const int j0 = __builtin_amdgcn_readlane(cv, k), j1 = __builtin_amdgcn_readlane(cv, k1i);
+        const int64_t e0 = __builtin_amdgcn_readlane(pv, k), e1 = __builtin_amdgcn_readlane(pv, k1i);
+        const float4* kp0 = reinterpret_cast<const float4*>(R.k + static_cast<int64_t>(j0) * R.ld);
+        const float4* vp0 = reinterpret_cast<const float4*>(R.v + static_cast<int64_t>(j0) * R.ld);
+        const float4* kp1 = reinterpret_cast<const float4*>(R.k + static_cast<int64_t>(j1) * R.ld);
+        const float4* vp1 = reinterpret_cast<const float4*>(R.v + static_cast<int64_t>(j1) * R.ld);
+        float4 k0[CH], v0[CH], k1[CH], v1[CH];
 #pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        const float4 kv = on[c] ? kp[c * 64 + lane] : f4z();
-        const float4 vv = on[c] ? vp[c * 64 + lane] : f4z();
-        const float dot = group_sum(dot4(qv[c], kv), gl);
-        const float alpha = expf(dot * ps[c] - mrow[c]) * linv[c];
-        const float da = group_sum(dot4(dmv[c], vv), gl);
-        const float ds = alpha * (da - dsum[c]);
-        const float g = ds * ps[c];
-        dqa[c].x = fmaf(g, kv.x, dqa[c].x);
-        dqa[c].y = fmaf(g, kv.y, dqa[c].y);
-        dqa[c].z = fmaf(g, kv.z, dqa[c].z);
-        dqa[c].w = fmaf(g, kv.w, dqa[c].w);
-        if (lead[c]) {
-          R.alpha[e * a.heads + head[c]] = alpha;
-          R.gs[e * a.heads + head[c]] = g;
-          R.tdot[e * a.heads + head[c]] = ds * dot;
+        for (int c = 0; c < CH; ++c) {
+          k0[c] = on[c] ? kp0[c * 64 + lane] : f4z();
+          k1[c] = on[c] ? kp1[c * 64 + lane] : f4z();
+          v0[c] = on[c] ? vp0[c * 64 + lane] : f4z();
+          v1[c] = on[c] ? vp1[c * 64 + lane] : f4z();
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const float dot0 = group_sum(dot4(qv[c], k0[c]), gl), dot1 = group_sum(dot4(qv[c], k1[c]), gl);
+          const float da0 = group_sum(dot4(dmv[c], v0[c]), gl), da1 = group_sum(dot4(dmv[c], v1[c]), gl);
+          const float al0 = __expf(dot0 * ps[c] - mrow[c]) * linv[c];
+          const float al1 = two ? __expf(dot1 * ps[c] - mrow[c]) * linv[c] : 0.f;
+          const float ds0 = al0 * (da0 - dsum[c]), ds1 = al1 * (da1 - dsum[c]);
+          const float g0 = ds0 * ps[c], g1 = ds1 * ps[c];
+          dqa[c].x = fmaf(g0, k0[c].x, fmaf(g1, k1[c].x, dqa[c].x));
+          dqa[c].y = fmaf(g0, k0[c].y, fmaf(g1, k1[c].y, dqa[c].y));
+          dqa[c].z = fmaf(g0, k0[c].z, fmaf(g1, k1[c].z, dqa[c].z));
+          dqa[c].w = fmaf(g0, k0[c].w, fmaf(g1, k1[c].w, dqa[c].w));
+          if (lead[c]) {
+            R.alpha[e0 * a.heads + head[c]] = al0;
+            R.gs[e0 * a.heads + head[c]] = g0;
+            R.tdot[e0 * a.heads + head[c]] = ds0 * dot0;
+            if (two) {
+              R.alpha[e1 * a.heads + head[c]] = al1;
+              R.gs[e1 * a.heads + head[c]] = g1;
+              R.tdot[e1 * a.heads + head[c]] = ds1 * dot1;
+            }
+          }
         }
       }
     }
@@ -218,25 +266,34 @@ __global__ __launch_bounds__(256) void k_hgt_bwd_src(const int32_t* __restrict__
     dka[c] = f4z();
     dva[c] = f4z();
   }
-  const int start = rowptr[row];
-  const int end = (rowend != nullptr) ? rowend[row] : rowptr[row + 1];
-  for (int p = start; p < end; ++p) {
-    const int i = __builtin_amdgcn_readfirstlane(col[p]);
-    if (i >= a.col_limit) continue;
-    const int64_t e = __builtin_amdgcn_readfirstlane(perm[p]);
-    const float4* qp = reinterpret_cast<const float4*>(a.q + static_cast<int64_t>(i) * a.ld_q);
-    const float4* dp = reinterpret_cast<const float4*>(dm + static_cast<int64_t>(i) * ld_dm);
+  const int start = ((hk_i32p)rowptr)[row];
+  const int end = (rowend != nullptr) ? ((hk_i32p)rowend)[row] : ((hk_i32p)rowptr)[row + 1];
+  const int n = end - start;
+  for (int base = 0; base < n; base += 64) {
+    const int mcnt = (n - base) < 64 ? (n - base) : 64;
+    const int cv = lane < mcnt ? col[start + base + lane] : 0;
+    const int pv = lane < mcnt ? perm[start + base + lane] : 0;
+    for (int k = 0; k < mcnt; k += 2) {
+      const int k1i = k + 1 < mcnt ? k + 1 : k;
+      const int i0 = __builtin_amdgcn_readlane(cv, k), i1 = __builtin_amdgcn_readlane(cv, k1i);
+      const bool ok0 = i0 < a.col_limit, ok1 = (k + 1 < mcnt) && i1 < a.col_limit;      // wave-uniform
+      const int is0 = ok0 ? i0 : 0, is1 = ok1 ? i1 : 0;                                   // dropped edges read row 0, weight 0
+      const int64_t e0 = __builtin_amdgcn_readlane(pv, k), e1 = __builtin_amdgcn_readlane(pv, k1i);
+      const float4* qp0 = reinterpret_cast<const float4*>(a.q + static_cast<int64_t>(is0) * a.ld_q);
+      const float4* dp0 = reinterpret_cast<const float4*>(dm + static_cast<int64_t>(is0) * ld_dm);
+      const float4* qp1 = reinterpret_cast<const float4*>(a.q + static_cast<int64_t>(is1) * a.ld_q);
+      const float4* dp1 = reinterpret_cast<const float4*>(dm + static_cast<int64_t>(is1) * ld_dm);
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      if (!on[c]) continue;
-      const float al = alpha[e * a.heads + head[c]];
-      const float g = gs[e * a.heads + head[c]];
-      const float4 qv = qp[c * 64 + lane];
-      const float4 dv4 = dp[c * 64 + lane];
-      dva[c].x = fmaf(al, dv4.x, dva[c].x); dva[c].y = fmaf(al, dv4.y, dva[c].y);
-      dva[c].z = fmaf(al, dv4.z, dva[c].z); dva[c].w = fmaf(al, dv4.w, dva[c].w);
-      dka[c].x = fmaf(g, qv.x, dka[c].x); dka[c].y = fmaf(g, qv.y, dka[c].y);
-      dka[c].z = fmaf(g, qv.z, dka[c].z); dka[c].w = fmaf(g, qv.w, dka[c].w);
+      for (int c = 0; c < CH; ++c) {
+        if (!on[c]) continue;
+        const float4 q0 = qp0[c * 64 + lane], d0 = dp0[c * 64 + lane], q1 = qp1[c * 64 + lane], d1 = dp1[c * 64 + lane];
+        const float al0 = ok0 ? alpha[e0 * a.heads + head[c]] : 0.f, g0 = ok0 ? gs[e0 * a.heads + head[c]] : 0.f;
+        const float al1 = ok1 ? alpha[e1 * a.heads + head[c]] : 0.f, g1 = ok1 ? gs[e1 * a.heads + head[c]] : 0.f;
+        dva[c].x = fmaf(al0, d0.x, fmaf(al1, d1.x, dva[c].x)); dva[c].y = fmaf(al0, d0.y, fmaf(al1, d1.y, dva[c].y));
+        dva[c].z = fmaf(al0, d0.z, fmaf(al1, d1.z, dva[c].z)); dva[c].w = fmaf(al0, d0.w, fmaf(al1, d1.w, dva[c].w));
+        dka[c].x = fmaf(g0, q0.x, fmaf(g1, q1.x, dka[c].x)); dka[c].y = fmaf(g0, q0.y, fmaf(g1, q1.y, dka[c].y));
+        dka[c].z = fmaf(g0, q0.z, fmaf(g1, q1.z, dka[c].z)); dka[c].w = fmaf(g0, q0.w, fmaf(g1, q1.w, dka[c].w));
+      }
     }
   }
   float4* okp = reinterpret_cast<float4*>(dk + static_cast<int64_t>(row) * ld_o);

@@ -627,7 +627,8 @@ class HGTConv(nn.Module):
         out = {}
         for t, m in zip(types, ms):
             x, n = x_dict[t], n_of[t]
-            o = self.out_lin.lins[t](F.gelu(m))
+            lo = self.out_lin.lins[t]
+            o = linear(F.gelu(m), lo.weight, lo.bias)
             if o.shape[-1] == x.shape[-1]:
                 o = torch.lerp(x if n >= x.shape[0] else x[:n], o, torch.sigmoid(self.skip[t]))
             out[t] = o
