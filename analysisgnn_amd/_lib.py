@@ -49,7 +49,7 @@ class Rel(C.Structure):
 class HgtRel(C.Structure):
     _fields_ = [("k", C.c_void_p), ("v", C.c_void_p), ("rowptr", C.c_void_p), ("rowend", C.c_void_p),
                 ("col", C.c_void_p), ("perm", C.c_void_p), ("pscale", C.c_void_p), ("ld", C.c_int64),
-                ("alpha", C.c_void_p), ("gs", C.c_void_p), ("tdot", C.c_void_p)]
+                ("alpha", C.c_void_p), ("gs", C.c_void_p), ("tdot", C.c_void_p), ("ld_tdot", C.c_int64)]
 
 
 class Gated(C.Structure):

@@ -224,11 +224,11 @@ __global__ __launch_bounds__(256) void k_hgt_bwd_dst(HgtTable t, HgtArgs a, cons
           if (lead[c]) {
             R.alpha[e0 * a.heads + head[c]] = al0;
             R.gs[e0 * a.heads + head[c]] = g0;
-            R.tdot[e0 * a.heads + head[c]] = ds0 * dot0;
+            R.tdot[R.ld_tdot > 0 ? head[c] * R.ld_tdot + e0 : e0 * a.heads + head[c]] = ds0 * dot0;
             if (two) {
               R.alpha[e1 * a.heads + head[c]] = al1;
               R.gs[e1 * a.heads + head[c]] = g1;
-              R.tdot[e1 * a.heads + head[c]] = ds1 * dot1;
+              R.tdot[R.ld_tdot > 0 ? head[c] * R.ld_tdot + e1 : e1 * a.heads + head[c]] = ds1 * dot1;
             }
           }
         }

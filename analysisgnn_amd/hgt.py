@@ -334,8 +334,12 @@ class _HGTCore(torch.autograd.Function):
         for s_t, e_ids in plan.src_rels.items():
             x = X[s_t]
             N, R = x.shape[0], len(e_ids)
-            sel = _index_tensor(tuple(e * heads + h for e in e_ids for h in range(heads)), dev)
-            Wk[s_t], Wv[s_t] = wk.detach().index_select(0, sel), wv.detach().index_select(0, sel)
+            ids = tuple(e * heads + h for e in e_ids for h in range(heads))
+            if ids == tuple(range(wk.shape[0])) and wk.is_contiguous() and wv.is_contiguous() and wk.data_ptr() % 16 == 0 and wv.data_ptr() % 16 == 0:
+                Wk[s_t], Wv[s_t] = wk.detach(), wv.detach()          # every relation leaves this type, in order: no gather
+            else:
+                sel = _index_tensor(ids, dev)
+                Wk[s_t], Wv[s_t] = wk.detach().index_select(0, sel), wv.detach().index_select(0, sel)
             kp[s_t] = torch.empty((N, R * H), dtype=torch.float32, device=dev)
             vp[s_t] = torch.empty((N, R * H), dtype=torch.float32, device=dev)
             if N > 0:
@@ -435,15 +439,17 @@ class _HGTCore(torch.autograd.Function):
                 offs.append(offs[-1] + k_)
             a_all = torch.empty((offs[-1], heads), dtype=torch.float32, device=dev)
             g_all = torch.empty((offs[-1], heads), dtype=torch.float32, device=dev)
-            # tdot as [R, max E_r, heads] (zero padded): the per-relation sums over edges are ONE reduction instead of R
-            t3 = torch.zeros((R, max(ne), heads), dtype=torch.float32, device=dev)
-            extra = [(a_all[offs[r]:offs[r + 1]], g_all[offs[r]:offs[r + 1]], t3[r, :ne[r]]) for r in range(R)]
+            # tdot head-major as [R, heads, max E_r] (zero padded): the sums over the edges are ONE contiguous reduction
+            t3 = torch.zeros((R, heads, max(ne)), dtype=torch.float32, device=dev)
+            extra = [(a_all[offs[r]:offs[r + 1]], g_all[offs[r]:offs[r + 1]], t3[r]) for r in range(R)]
             arr, keep = _HGTCore._rel_table(plan, rels, kp, vp, ps, H, extra)
+            for r in range(R):
+                arr[r].ld_tdot = max(ne)
             dq_ptr = dkqv[t].data_ptr() + 4 * H
             _lib.check(lib.agnn_hgt_attn_bwd_dst_f32(R, arr, q.data_ptr() + 4 * H, q.stride(0), dm.data_ptr(), dm.stride(0), out.data_ptr(),
                                                      out.stride(0), m.data_ptr(), linv.data_ptr(), n, H, heads, dq_ptr, dkqv[t].stride(0), st),
                        "agnn_hgt_attn_bwd_dst_f32")
-            dps_rows.append(t3.sum(dim=1))
+            dps_rows.append(t3.sum(dim=2))
             dps_ids += [e_idx for e_idx, _ in rels]
             for r, (e_idx, et) in enumerate(rels):
                 s_t, blk = plan.block_of[e_idx]
@@ -494,15 +500,22 @@ class _HGTCore(torch.autograd.Function):
             for it, (off, dy, y) in zip(items, ((0, dkp[s_t], dWk), (2 * H, dvp[s_t], dWv))):
                 it.x, it.w, it.y, it.ld_x, it.ld_y = x.data_ptr() + 4 * off, dy.data_ptr(), y.data_ptr(), x.stride(0), dy.stride(0)
             _lib.check(lib.agnn_relt_dw_f32(2, items, R, heads, D, N, ws.data_ptr(), nws, st), "agnn_relt_dw_f32")
-            sel = _index_tensor(tuple(e * heads + h for e in e_ids for h in range(heads)), dev)
+            ids = tuple(e * heads + h for e in e_ids for h in range(heads))
+            if gwk is None and ids == tuple(range(wk_shape[0])) and len(ctx.srcs) == 1:
+                gwk, gwv = dWk, dWv                                  # the one source type covers the whole parameter
+                continue
             if gwk is None:
                 gwk = torch.zeros(wk_shape, dtype=torch.float32, device=dev)
                 gwv = torch.zeros(wv_shape, dtype=torch.float32, device=dev)
+            sel = _index_tensor(ids, dev)
             gwk.index_copy_(0, sel, dWk)
             gwv.index_copy_(0, sel, dWv)
-        dp_all = torch.zeros(p_shape, dtype=torch.float32, device=dev)
-        if dps_rows:
-            dp_all.index_copy_(0, _index_tensor(tuple(dps_ids), dev), torch.cat(dps_rows, dim=0) * (1.0 / math.sqrt(D)))
+        if dps_rows and tuple(dps_ids) == tuple(range(p_shape[0])):
+            dp_all = (torch.cat(dps_rows, dim=0) * (1.0 / math.sqrt(D))).view(p_shape)
+        else:
+            dp_all = torch.zeros(p_shape, dtype=torch.float32, device=dev)
+            if dps_rows:
+                dp_all.index_copy_(0, _index_tensor(tuple(dps_ids), dev), torch.cat(dps_rows, dim=0) * (1.0 / math.sqrt(D)))
         return (None, gwk, gwv, dp_all, *[None if t in dead else dkqv[t] for t in plan.types])
 
 

@@ -207,7 +207,8 @@ typedef struct {
   int64_t ld;
   float* alpha;            /* (device) [n_edges, heads]  backward outputs */
   float* gs;               /* (device) [n_edges, heads] */
-  float* tdot;             /* (device) [n_edges, heads] */
+  float* tdot;             /* (device) [n_edges, heads], or head-major [heads, ld_tdot] when ld_tdot > 0 */
+  int64_t ld_tdot;         /* 0: edge-major tdot; > 0: tdot[h * ld_tdot + e] (a contiguous sum over the edges per head) */
 } agnn_hgt_rel_t;
 
 int agnn_hgt_attn_fwd_f32(int n_rel, const agnn_hgt_rel_t* rels /* (host) */, const float* q, int64_t ld_q,
