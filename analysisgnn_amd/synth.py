@@ -314,10 +314,15 @@ def torch_inputs(g: ScoreGraph, in_channels: int = 25, device="cpu", seed: int =
     gen = torch.Generator().manual_seed(seed)
     x_dict = {t: torch.randn(n, in_channels, generator=gen).to(device) for t, n in g.num_nodes.items()}
     n_note = g.num_nodes["note"]
+    batch_dict = {t: torch.from_numpy(b).to(device) for t, b in g.batch.items()}
+    bs = int(g.batch_size if g.batch_size is not None else n_note)
+    # the per-subgraph target counts are host knowledge at collation time: carried with the batch tensor so that the
+    # sequence branch does not have to read them back from the device (`bincount(batch).tolist()`, models/analysis.py:529-530)
+    batch_dict["note"].agnn_target_lengths = np.bincount(g.batch["note"][:bs], minlength=g.num_graphs).tolist()
     return dict(
         x_dict=x_dict,
         edge_index_dict={et: torch.from_numpy(np.ascontiguousarray(e)).to(device) for et, e in g.edge_index.items()},
-        batch_dict={t: torch.from_numpy(b).to(device) for t, b in g.batch.items()},
+        batch_dict=batch_dict,
         pitch_spelling=torch.randint(0, 35, (n_note,), generator=gen).to(device),
         key_signature=torch.randint(0, 15, (n_note,), generator=gen).to(device),
         batch_size=int(g.batch_size if g.batch_size is not None else n_note),
