@@ -1,0 +1,139 @@
+"""Device-side batch assembly: the scores of a corpus stay resident in HBM and every training
+batch — windows of target notes plus their sampled hop neighbours, block-diagonal over the subgraphs, hop-ordered as
+PyG's NeighborLoader lays it out — is produced by ONE kernel launch (`agnn_sample_hops`) into buffers of static shape.
+Replaces graphmuse's `MuseNeighborLoader`, its collation and the host-to-device copy of every batch
+(reference analysisgnn/data/datamodules/analysis.py:270-293; consumed at models/analysis.py:948-961).
+
+Static shapes are what lets the WHOLE step (sampling, feature gather, CSR build, forward, backward, optimizer) be captured
+once and replayed with a different batch every time: hop blocks are padded to a capacity, padding nodes carry no features
+and no edges, padding edge slots hold (-1, -1) and are dropped by the CSR build, and `num_sampled_nodes/edges` are the
+capacities, so `trim_to_layer` trims whole padded blocks.  Only the 32 window starts cross the PCIe bus per step.
+Note-only graphs (the relations among notes), as `synth.sample_hops`.  No CPU path."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .graph import SegSpec, build_csr
+
+EdgeType = Tuple[str, str, str]
+
+
+class ScoreStore:
+    """All scores of a corpus on the device: note features / attributes concatenated over the scores (global note ids) and,
+    per relation, one CSR by DESTINATION over all notes (built once with `agnn_csr_build`)."""
+
+    def __init__(self, graphs: Sequence, in_channels: int, device, tasks: Optional[Dict[str, int]] = None, seed: int = 0):
+        """`graphs`: synth.ScoreGraph objects (numpy).  Features / spellings / keys / labels are synthetic (seeded), as
+        everywhere in this repo: the reference's datasets cannot be fetched offline."""
+        dev = torch.device(device)
+        self.device = dev
+        self.edge_types: List[EdgeType] = [et for et in graphs[0].edge_types if et[0] == "note" and et[2] == "note"]
+        sizes = [int(g.num_nodes["note"]) for g in graphs]
+        self.score_start = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        n = int(self.score_start[-1])
+        self.num_notes = n
+        gen = torch.Generator().manual_seed(seed)
+        width = (in_channels + 3) & ~3                       # feature rows padded to 16 bytes (zero spare columns)
+        x = torch.zeros(n, width)
+        x[:, :in_channels] = torch.randn(n, in_channels, generator=gen)
+        self.in_channels = in_channels
+        self.x = x.to(dev)
+        attrs = [torch.randint(0, 35, (n,), generator=gen), torch.randint(0, 15, (n,), generator=gen)]
+        self.tasks = dict(tasks) if tasks else {}
+        for c in self.tasks.values():
+            attrs.append(torch.randint(0, c, (n,), generator=gen))
+        self.attrs = torch.stack(attrs).to(dev)              # int64 [2 + T, n]: pitch spelling, key signature, labels
+        self.onset_div = torch.from_numpy(np.concatenate([g.onset_div for g in graphs])).to(dev)
+        specs, self._keep = [], []
+        for et in self.edge_types:
+            src = np.concatenate([g.edge_index[et][0] + o for g, o in zip(graphs, self.score_start[:-1])])
+            dst = np.concatenate([g.edge_index[et][1] + o for g, o in zip(graphs, self.score_start[:-1])])
+            s_t, d_t = torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev)
+            self._keep += [s_t, d_t]
+            specs.append(SegSpec(row=d_t, col=s_t, n_rows=n))
+        self.csr = build_csr(specs)                          # rows = destination note, col = source note
+
+    def random_windows(self, n_sub: int, n_targets: int, rng: np.random.Generator) -> np.ndarray:
+        """What the loader's sampler decides on the host: `n_sub` (score, first target) pairs -> global ids, int32."""
+        ok = np.nonzero(np.diff(self.score_start) >= n_targets)[0]
+        scores = rng.choice(ok, size=n_sub, replace=len(ok) < n_sub)
+        lo = self.score_start[scores]
+        hi = self.score_start[scores + 1] - n_targets
+        return (lo + (rng.random(n_sub) * (hi - lo + 1)).astype(np.int64)).astype(np.int32)
+
+
+class DeviceSampler:
+    """Static-shape sampled batches out of a `ScoreStore`.  `sample()` refills the same tensors every call (a captured
+    graph replays it); `batch` is the dict `TorchAnalysisGNN.encode` consumes (the keys of `synth.torch_inputs`)."""
+
+    def __init__(self, store: ScoreStore, n_sub: int, n_targets: int = 500, num_neighbors: Sequence[int] = (5, 5),
+                 capacity: Sequence[int] = (64, 64), seed: int = 0):
+        if len(capacity) != len(num_neighbors):
+            raise ValueError("one capacity per hop")
+        self.store, self.n_sub, self.n_targets = store, int(n_sub), int(n_targets)
+        self.fan, self.cap = [int(v) for v in num_neighbors], [int(v) for v in capacity]
+        dev = store.device
+        lib = _lib.load()
+        cfg = _lib.Sampler()
+        cfg.n_rel = len(store.edge_types)
+        for r, csr in enumerate(store.csr):
+            cfg.rowptr[r], cfg.col[r] = csr.rowptr.data_ptr(), csr.col.data_ptr()
+        cfg.n_sub, cfg.n_targets, cfg.n_hops = self.n_sub, self.n_targets, len(self.fan)
+        for h, (f, c) in enumerate(zip(self.fan, self.cap)):
+            cfg.fan[h], cfg.cap[h] = f, c
+        self.num_nodes = int(lib.agnn_sampler_num_nodes(cfg))
+        self.e_cap = int(lib.agnn_sampler_edge_capacity(cfg))
+        if self.num_nodes < 0 or self.e_cap < 0:
+            raise _lib.AgnnError("bad sampler configuration")
+        self.win_start = torch.zeros(self.n_sub, dtype=torch.int32, device=dev)
+        self.rng = torch.tensor([int(seed), 0], dtype=torch.int64, device=dev)       # (seed, step): bump step per batch
+        self.node_gid = torch.empty(self.num_nodes, dtype=torch.int32, device=dev)
+        self.edges = {et: torch.empty((2, self.e_cap), dtype=torch.int64, device=dev) for et in store.edge_types}
+        cfg.win_start, cfg.rng, cfg.node_gid = self.win_start.data_ptr(), self.rng.data_ptr(), self.node_gid.data_ptr()
+        for r, et in enumerate(store.edge_types):
+            cfg.edges[r] = self.edges[et].data_ptr()
+        cfg.e_cap = self.e_cap
+        cfg.status = _lib.status_word(dev).data_ptr()
+        self._cfg = cfg
+        B, T = self.n_sub, self.n_targets
+        self.batch_size = B * T
+        # static per-hop capacities = what trim_to_layer is driven by (PyG num_sampled_nodes / num_sampled_edges)
+        self.num_sampled_nodes = {"note": [B * T] + [B * c for c in self.cap]}
+        e_per_hop, F = [], T
+        for f, c in zip(self.fan, self.cap):
+            e_per_hop.append(B * F * f)
+            F = c
+        self.num_sampled_edges = {et: list(e_per_hop) for et in store.edge_types}
+        sub = [np.repeat(np.arange(B), T)] + [np.repeat(np.arange(B), c) for c in self.cap]
+        self.batch_note = torch.from_numpy(np.concatenate(sub).astype(np.int64)).to(dev)
+        self.batch_note.agnn_target_lengths = [T] * B
+        self.x = torch.empty((self.num_nodes, store.x.shape[1]), dtype=torch.float32, device=dev)
+        self.attrs = torch.empty((store.attrs.shape[0], self.num_nodes), dtype=torch.int64, device=dev)
+        self.batch = dict(
+            x_dict={"note": self.x[:, :store.in_channels]}, edge_index_dict=self.edges, batch_dict={"note": self.batch_note},
+            pitch_spelling=self.attrs[0], key_signature=self.attrs[1], batch_size=self.batch_size,
+            neighbor_mask_node=self.num_sampled_nodes, neighbor_mask_edge=self.num_sampled_edges,
+            labels={t: self.attrs[2 + i, :self.batch_size] for i, t in enumerate(store.tasks)},
+            label_matrix=self.attrs[2:, :self.batch_size])
+
+    def set_windows(self, win_start: np.ndarray) -> None:
+        """The only per-batch host-to-device traffic: n_sub int32 (outside the captured graph, like any input refill)."""
+        self.win_start.copy_(torch.from_numpy(np.ascontiguousarray(win_start, dtype=np.int32)), non_blocking=True)
+
+    def sample(self) -> dict:
+        """Advance the step counter, sample, gather features and attributes — four launches, graph-capturable."""
+        dev = self.store.device
+        lib = _lib.load()
+        st = _lib.stream_ptr(dev)
+        self.rng[1:2].add_(1)
+        _lib.check(lib.agnn_sample_hops(self._cfg, st), "agnn_sample_hops")
+        s = self.store
+        _lib.check(lib.agnn_gather_rows_f32(s.x.data_ptr(), s.x.stride(0), self.node_gid.data_ptr(), self.num_nodes, s.x.shape[1],
+                                            self.x.data_ptr(), self.x.stride(0), st), "agnn_gather_rows_f32")
+        _lib.check(lib.agnn_gather_i64(s.attrs.data_ptr(), s.attrs.stride(0), self.node_gid.data_ptr(), self.num_nodes, s.attrs.shape[0], 0,
+                                       self.attrs.data_ptr(), self.attrs.stride(0), st), "agnn_gather_i64")
+        return self.batch

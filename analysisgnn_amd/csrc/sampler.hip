@@ -1,0 +1,277 @@
+// Device-side batch assembly: neighbour sampling of note windows out of score graphs that are RESIDENT in HBM.
+//
+// The reference assembles every training batch on the host: graphmuse's `MuseNeighborLoader` (reference
+// analysisgnn/data/datamodules/analysis.py:270-293: subgraph_size = 500 target notes per window, num_neighbors =
+// [5] * (num_layers - 1), batch_size windows per batch, worker processes, then a host-to-device copy) hands over a
+// hop-ordered HeteroData whose per-hop counts drive PyG's trim_to_layer.  At a few milliseconds per training step that
+// loader is the bottleneck, and its batches have data-dependent shapes, which a replayed hipGraph cannot take.
+// Here the scores stay on the device (one CSR by destination per relation over ALL notes of ALL scores: 288 GB of HBM
+// hold any corpus of this kind) and ONE launch samples a whole batch into buffers of STATIC shape:
+//   * nodes:  [ n_sub * n_targets targets | n_sub * cap[0] hop-1 slots | n_sub * cap[1] hop-2 slots | ... ]; a subgraph's
+//     new nodes of a hop fill its slots in ascending global id, the rest are padding (gid -1: no features, no edges);
+//   * edges of relation r:  hop h owns n_sub * F_h * fan[h] slots (F_1 = n_targets, F_h = cap[h-2]), slot
+//     ((s * F_h + i) * fan + k) belongs to the k-th sampled in-neighbour of frontier node i of subgraph s — no
+//     compaction, no atomics on the edge list; unused slots hold (-1, -1), which agnn_csr_build drops.
+// Hop-ordered as PyG's NeighborLoader lays a batch out, so `trim_to_layer` with the STATIC per-hop capacities
+// (num_sampled_nodes = [n_sub*n_targets, n_sub*cap[0], ...], num_sampled_edges[r] = [n_sub*F_1*fan[0], ...]) trims
+// exactly the padded hop blocks: the whole training step, sampler included, is one fixed launch sequence.
+// Sampling: all in-neighbours when a node has at most `fan` of them (the usual case in a score graph), otherwise
+// `fan` of them without replacement by selection sampling (Knuth's algorithm S) on Philox-4x32-10 keyed by
+// (seed; step, destination, relation, hop): the batch is a pure function of (windows, seed, step) — bitwise
+// reproducible, checked against oracle/sampler_ref.py.
+// One workgroup per subgraph; new nodes are collected in an LDS hash set, sorted, numbered; integer work only.
+#include "agnn_common.h"
+
+namespace {
+
+constexpr int kHash = 1024;       // LDS hash set of the non-window nodes of one subgraph (<= sum of caps, <= 512)
+constexpr int kNewMax = 512;      // candidates of one hop before the cut to cap[h]
+constexpr int kEmpty = -1;
+
+struct SamplerArgs {
+  agnn_sampler_t c;
+};
+
+__device__ __forceinline__ uint32_t s_mulhi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+
+__device__ __forceinline__ uint4 s_philox(uint4 c, uint2 k) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t h0 = s_mulhi(0xD2511F53u, c.x), l0 = 0xD2511F53u * c.x;
+    const uint32_t h1 = s_mulhi(0xCD9E8D57u, c.z), l1 = 0xCD9E8D57u * c.z;
+    c = make_uint4(h1 ^ c.y ^ k.x, l1, h0 ^ c.w ^ k.y, l0);
+    k.x += 0x9E3779B9u;
+    k.y += 0xBB67AE85u;
+  }
+  return c;
+}
+
+// Positions (into the in-neighbour list of length deg) of the sampled neighbours, ascending; returns how many.
+__device__ __forceinline__ int select_positions(int deg, int fan, uint32_t dst, uint32_t tag, uint32_t step, uint2 key, int* pos) {
+  if (deg <= fan) {
+    for (int k = 0; k < deg; ++k) pos[k] = k;
+    return deg;
+  }
+  int m = 0;
+  uint4 rnd = make_uint4(0, 0, 0, 0);
+  for (int t = 0; t < deg && m < fan; ++t) {
+    if ((t & 3) == 0) rnd = s_philox(make_uint4(dst, tag, static_cast<uint32_t>(t >> 2), step), key);
+    const uint32_t u = (t & 3) == 0 ? rnd.x : (t & 3) == 1 ? rnd.y : (t & 3) == 2 ? rnd.z : rnd.w;
+    // select with probability (fan - m) / (deg - t)
+    if (s_mulhi(u, static_cast<uint32_t>(deg - t)) < static_cast<uint32_t>(fan - m)) pos[m++] = t;
+  }
+  return m;
+}
+
+__device__ __forceinline__ uint32_t hslot(int gid) { return (static_cast<uint32_t>(gid) * 2654435761u) >> 22; }   // 10 bits
+
+__global__ __launch_bounds__(256) void k_sample_hops(SamplerArgs A) {
+  const agnn_sampler_t& c = A.c;
+  __shared__ int hkey[kHash];
+  __shared__ int hval[kHash];
+  __shared__ int newl[kNewMax];
+  __shared__ int fr_gid[AGNN_SAMPLER_MAX_CAP];
+  __shared__ int n_new, n_drop;
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int T = c.n_targets;
+  const int w = c.win_start[s];
+  const uint2 key = make_uint2(static_cast<uint32_t>(c.rng[0]), static_cast<uint32_t>(static_cast<uint64_t>(c.rng[0]) >> 32));
+  const uint32_t step = static_cast<uint32_t>(c.rng[1]);
+  for (int i = tid; i < kHash; i += 256) { hkey[i] = kEmpty; hval[i] = -1; }
+  for (int i = tid; i < T; i += 256) c.node_gid[static_cast<int64_t>(s) * T + i] = w + i;
+  if (tid == 0) n_drop = 0;
+  __syncthreads();
+
+  int64_t nbase = static_cast<int64_t>(c.n_sub) * T;          // first batch node of this hop's block
+  int64_t ebase = 0;                                            // first edge slot of this hop's block (same for every relation)
+  int F = T, Fcap = T;                                          // frontier: actual size, slots
+  int64_t fr_local0 = static_cast<int64_t>(s) * T;             // batch id of frontier node 0
+  for (int h = 0; h < c.n_hops; ++h) {
+    const int fan = c.fan[h], cap = c.cap[h];
+    if (tid == 0) n_new = 0;
+    for (int i = tid; i < kNewMax; i += 256) newl[i] = 0x7fffffff;
+    __syncthreads();
+    // ---- A: the sampled sources that are neither in the window nor known yet
+    for (int it = tid; it < F * c.n_rel; it += 256) {
+      const int i = it / c.n_rel, r = it - i * c.n_rel;
+      const int dst = h == 0 ? w + i : fr_gid[i];
+      const int st = c.rowptr[r][dst], deg = c.rowptr[r][dst + 1] - st;
+      int pos[AGNN_SAMPLER_MAX_FAN];
+      const int cnt = select_positions(deg, fan, static_cast<uint32_t>(dst), static_cast<uint32_t>(r + (h << 8)), step, key, pos);
+      for (int k = 0; k < cnt; ++k) {
+        const int src = c.col[r][st + pos[k]];
+        if (src >= w && src < w + T) continue;
+        uint32_t q = hslot(src);
+        for (int probe = 0; probe < kHash; ++probe, q = (q + 1) & (kHash - 1)) {
+          const int old = atomicCAS(&hkey[q], kEmpty, src);
+          if (old == kEmpty) {                              // first sight of this node
+            const int idx = atomicAdd(&n_new, 1);
+            if (idx < kNewMax) newl[idx] = src;
+            break;
+          }
+          if (old == src) break;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- B: ascending global id (bitonic sort of the padded list), the first `cap` get this hop's slots
+    for (int k2 = 2; k2 <= kNewMax; k2 <<= 1) {
+      for (int j = k2 >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < kNewMax; i += 256) {
+          const int ixj = i ^ j;
+          if (ixj > i) {
+            const int a = newl[i], b = newl[ixj];
+            const bool up = (i & k2) == 0;
+            if ((a > b) == up) { newl[i] = b; newl[ixj] = a; }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    const int found = n_new < kNewMax ? n_new : kNewMax;
+    const int kept = found < cap ? found : cap;
+    if (tid == 0 && n_new > kept) n_drop += n_new - kept;
+    for (int i = tid; i < cap; i += 256) {
+      const int g = i < kept ? newl[i] : -1;
+      c.node_gid[nbase + static_cast<int64_t>(s) * cap + i] = g;
+      if (i < kept) {
+        uint32_t q = hslot(g);
+        while (hkey[q] != g) q = (q + 1) & (kHash - 1);
+        hval[q] = static_cast<int>(nbase + static_cast<int64_t>(s) * cap + i);
+      }
+    }
+    __syncthreads();
+    // ---- C: the edges, every (frontier node, relation, k) in its own slot
+    for (int it = tid; it < Fcap * c.n_rel; it += 256) {
+      const int i = it / c.n_rel, r = it - i * c.n_rel;
+      int64_t* e0 = c.edges[r] + ebase + (static_cast<int64_t>(s) * Fcap + i) * fan;
+      int64_t* e1 = e0 + c.e_cap;
+      int cnt = 0, st = 0;
+      int pos[AGNN_SAMPLER_MAX_FAN];
+      if (i < F) {
+        const int dst = h == 0 ? w + i : fr_gid[i];
+        st = c.rowptr[r][dst];
+        const int deg = c.rowptr[r][dst + 1] - st;
+        cnt = select_positions(deg, fan, static_cast<uint32_t>(dst), static_cast<uint32_t>(r + (h << 8)), step, key, pos);
+      }
+      for (int k = 0; k < fan; ++k) {
+        int64_t src_l = -1;
+        if (k < cnt) {
+          const int src = c.col[r][st + pos[k]];
+          if (src >= w && src < w + T) {
+            src_l = static_cast<int64_t>(s) * T + (src - w);
+          } else {
+            uint32_t q = hslot(src);
+            while (hkey[q] != src && hkey[q] != kEmpty) q = (q + 1) & (kHash - 1);
+            src_l = hkey[q] == src ? hval[q] : -1;          // -1: dropped by the capacity cut
+          }
+        }
+        e0[k] = src_l;
+        e1[k] = src_l >= 0 ? fr_local0 + i : -1;
+      }
+    }
+    __syncthreads();
+    // ---- next frontier = this hop's new nodes, in slot order
+    for (int i = tid; i < cap; i += 256) fr_gid[i] = i < kept ? newl[i] : -1;
+    ebase += static_cast<int64_t>(c.n_sub) * Fcap * fan;
+    fr_local0 = nbase + static_cast<int64_t>(s) * cap;
+    nbase += static_cast<int64_t>(c.n_sub) * cap;
+    F = kept;
+    Fcap = cap;
+    __syncthreads();
+  }
+  if (tid == 0 && n_drop > 0 && c.status != nullptr) atomicAdd(c.status, n_drop);
+}
+
+// out[i, :] = gid[i] >= 0 ? src[gid[i], :] : 0   (float rows, H % 4 == 0; one 16-lane group per row)
+__global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ gid,
+                                                     int64_t n, int32_t H4, float* __restrict__ out, int64_t ld_out) {
+  const int64_t total = n * H4;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t i = e / H4;
+    const int c4 = static_cast<int>(e - i * H4);
+    const int g = gid[i];
+    const float4 v = g >= 0 ? *reinterpret_cast<const float4*>(src + static_cast<int64_t>(g) * ld_src + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(out + i * ld_out + 4 * c4) = v;
+  }
+}
+
+// out[t, i] = gid[i] >= 0 ? src[t * ld_src + gid[i]] : fill      (T int64 attribute vectors: labels, spelling, key)
+__global__ __launch_bounds__(256) void k_gather_i64(const int64_t* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ gid,
+                                                    int64_t n, int32_t T, int64_t fill, int64_t* __restrict__ out, int64_t ld_out) {
+  const int64_t total = n * T;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t t = e / n, i = e - t * n;
+    const int g = gid[i];
+    out[t * ld_out + i] = g >= 0 ? src[t * ld_src + g] : fill;
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t agnn_sampler_num_nodes(const agnn_sampler_t* c) {
+  if (!c) return -1;
+  int64_t n = static_cast<int64_t>(c->n_sub) * c->n_targets;
+  for (int h = 0; h < c->n_hops; ++h) n += static_cast<int64_t>(c->n_sub) * c->cap[h];
+  return n;
+}
+
+extern "C" int64_t agnn_sampler_edge_capacity(const agnn_sampler_t* c) {
+  if (!c) return -1;
+  int64_t e = 0, F = c->n_targets;
+  for (int h = 0; h < c->n_hops; ++h) {
+    e += static_cast<int64_t>(c->n_sub) * F * c->fan[h];
+    F = c->cap[h];
+  }
+  return e;
+}
+
+extern "C" int agnn_sample_hops(const agnn_sampler_t* cfg, agnn_stream_t stream_) {
+  using namespace agnn;
+  if (!cfg) return fail(AGNN_EINVAL, "sample_hops: null config");
+  const agnn_sampler_t& c = *cfg;
+  if (c.n_rel <= 0 || c.n_rel > AGNN_SAMPLER_MAX_REL) return fail(AGNN_EINVAL, "sample_hops: n_rel=%d not in [1,%d]", c.n_rel, AGNN_SAMPLER_MAX_REL);
+  if (c.n_hops <= 0 || c.n_hops > AGNN_SAMPLER_MAX_HOPS) return fail(AGNN_EINVAL, "sample_hops: n_hops=%d not in [1,%d]", c.n_hops, AGNN_SAMPLER_MAX_HOPS);
+  if (c.n_sub <= 0 || c.n_targets <= 0) return fail(AGNN_EINVAL, "sample_hops: n_sub=%d n_targets=%d", c.n_sub, c.n_targets);
+  int cap_sum = 0;
+  for (int h = 0; h < c.n_hops; ++h) {
+    if (c.fan[h] <= 0 || c.fan[h] > AGNN_SAMPLER_MAX_FAN) return fail(AGNN_EINVAL, "sample_hops: fan[%d]=%d not in [1,%d]", h, c.fan[h], AGNN_SAMPLER_MAX_FAN);
+    if (c.cap[h] <= 0 || c.cap[h] > AGNN_SAMPLER_MAX_CAP) return fail(AGNN_EINVAL, "sample_hops: cap[%d]=%d not in [1,%d]", h, c.cap[h], AGNN_SAMPLER_MAX_CAP);
+    cap_sum += c.cap[h];
+  }
+  if (cap_sum > kHash / 2) return fail(AGNN_EINVAL, "sample_hops: sum of capacities %d > %d", cap_sum, kHash / 2);
+  if (!c.win_start || !c.rng || !c.node_gid) return fail(AGNN_EINVAL, "sample_hops: null argument");
+  if (c.e_cap != agnn_sampler_edge_capacity(cfg)) return fail(AGNN_EINVAL, "sample_hops: e_cap=%lld, expected %lld", (long long)c.e_cap, (long long)agnn_sampler_edge_capacity(cfg));
+  for (int r = 0; r < c.n_rel; ++r)
+    if (!c.rowptr[r] || !c.col[r] || !c.edges[r]) return fail(AGNN_EINVAL, "sample_hops: relation %d incomplete", r);
+  SamplerArgs A{c};
+  hipLaunchKernelGGL(k_sample_hops, dim3(static_cast<unsigned>(c.n_sub)), dim3(256), 0, static_cast<hipStream_t>(stream_), A);
+  return check_launch("sample_hops");
+}
+
+extern "C" int agnn_gather_rows_f32(const float* src, int64_t ld_src, const int32_t* gid, int64_t n, int32_t H, float* out, int64_t ld_out,
+                                    agnn_stream_t stream_) {
+  using namespace agnn;
+  if (n < 0 || H <= 0 || (H & 3)) return fail(AGNN_EINVAL, "gather_rows: n=%lld H=%d (H must be a multiple of 4)", (long long)n, H);
+  if (n == 0) return AGNN_OK;
+  if (!src || !gid || !out) return fail(AGNN_EINVAL, "gather_rows: null argument");
+  if (!aligned16(src) || !aligned16(out) || (ld_src & 3) || (ld_out & 3) || ld_src < H || ld_out < H) return fail(AGNN_EALIGN, "gather_rows: rows must be 16-byte aligned");
+  int64_t blocks = (n * (H / 4) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_gather_rows, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream_), src, ld_src, gid, n, H / 4,
+                     out, ld_out);
+  return check_launch("gather_rows");
+}
+
+extern "C" int agnn_gather_i64(const int64_t* src, int64_t ld_src, const int32_t* gid, int64_t n, int32_t n_vec, int64_t fill, int64_t* out,
+                               int64_t ld_out, agnn_stream_t stream_) {
+  using namespace agnn;
+  if (n < 0 || n_vec <= 0) return fail(AGNN_EINVAL, "gather_i64: n=%lld n_vec=%d", (long long)n, n_vec);
+  if (n == 0) return AGNN_OK;
+  if (!src || !gid || !out || ld_out < n) return fail(AGNN_EINVAL, "gather_i64: null argument or ld_out < n");
+  int64_t blocks = (n * n_vec + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_gather_i64, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream_), src, ld_src, gid, n, n_vec, fill,
+                     out, ld_out);
+  return check_launch("gather_i64");
+}

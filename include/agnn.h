@@ -24,6 +24,7 @@
  *   agnn_gproj_*          the task heads' last Linear layers as one grouped projection (ref: models/analysis.py:486-496)
  *   agnn_adamw_f32        gradient clipping + `torch.optim.AdamW` step on the flat buffers (ref: models/analysis.py:1380-1381)
  *   agnn_multitask_ce_f32 the 21 per-task CrossEntropyLoss terms (ref: models/analysis.py:881-888)
+ *   agnn_sample_hops      graphmuse `MuseNeighborLoader` batch assembly (ref: data/datamodules/analysis.py:270-293)
  *   agnn_relt_*           PyG `HGTConv` per-head relation transforms (k_rel / v_rel)
  *   agnn_hgt_attn_*       PyG `HGTConv` message/softmax/aggregate, reached through graphmuse
  *                         `HybridHGT` (ref: models/analysis.py:445-453)
@@ -397,6 +398,50 @@ int agnn_train_loss_bwd_f32(const float* dlogits, int64_t ld, const int32_t* seg
                             int32_t n_cols, const float* inv_count, const float* g, float* out, int64_t ld_out,
                             const float* feat, int64_t ld_feat, int32_t feat_cols, float lambda_feat, float* dfeat,
                             int64_t ld_dfeat, agnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Device-side batch assembly: neighbour sampling of note windows out of score graphs resident in device memory
+ * (replaces graphmuse's `MuseNeighborLoader` + collation + host-to-device copy, ref data/datamodules/analysis.py:270-293:
+ * subgraph_size target notes per window, num_neighbors per hop, batch_size windows; PyG NeighborLoader layout consumed at
+ * models/analysis.py:948-961).  One launch fills buffers of STATIC shape (hop blocks padded to capacity), so the sampled
+ * batch — and with it the whole training step — is a fixed launch sequence a hipGraph can replay:
+ *   nodes  [ n_sub*n_targets | n_sub*cap[0] | n_sub*cap[1] | ... ]   node_gid = global note id, -1 in unused slots; a
+ *          subgraph's new nodes of a hop take its slots in ascending global id;
+ *   edges[r]  int64 [2, e_cap] (row 0 = source, row 1 = target, batch-local ids; (-1, -1) in unused slots, which
+ *          agnn_csr_build drops): hop h owns n_sub * F_h * fan[h] slots, F_1 = n_targets, F_h = cap[h-2]; slot
+ *          ((s*F_h + i)*fan[h] + k) = k-th sampled in-neighbour of frontier node i of subgraph s.
+ * rowptr / col: CSR by DESTINATION of every relation over all notes of all scores (int32).  All in-neighbours are taken
+ * when there are at most fan[h]; otherwise fan[h] of them without replacement (selection sampling on Philox-4x32-10 keyed
+ * by rng = (seed, step) and (destination, relation, hop)).  Hop h+1 expands only the nodes hop h added (PyG semantics).
+ * `status` (optional, as in agnn_csr_build) counts sources dropped because a hop produced more than cap[h] new nodes.
+ * agnn_gather_rows_f32 / agnn_gather_i64 fetch the batch's feature rows / integer attributes by node_gid (0 / `fill` for
+ * padding slots).
+ * ------------------------------------------------------------------------------------------ */
+#define AGNN_SAMPLER_MAX_REL 8
+#define AGNN_SAMPLER_MAX_HOPS 4
+#define AGNN_SAMPLER_MAX_FAN 16
+#define AGNN_SAMPLER_MAX_CAP 256
+typedef struct {
+  int32_t n_rel;
+  const int32_t* rowptr[AGNN_SAMPLER_MAX_REL];   /* (device) [n_notes_total + 1] */
+  const int32_t* col[AGNN_SAMPLER_MAX_REL];      /* (device) source note of every in-edge */
+  const int32_t* win_start;                      /* (device) [n_sub] global id of each window's first target note */
+  int32_t n_sub, n_targets, n_hops;
+  int32_t fan[AGNN_SAMPLER_MAX_HOPS];
+  int32_t cap[AGNN_SAMPLER_MAX_HOPS];
+  const int64_t* rng;                            /* (device) int64[2]: seed, step */
+  int32_t* node_gid;                             /* (device) out [agnn_sampler_num_nodes] */
+  int64_t* edges[AGNN_SAMPLER_MAX_REL];          /* (device) out, per relation int64 [2, e_cap] */
+  int64_t e_cap;                                 /* = agnn_sampler_edge_capacity */
+  int32_t* status;                               /* (device) int32[1] or NULL */
+} agnn_sampler_t;
+int64_t agnn_sampler_num_nodes(const agnn_sampler_t* cfg /* (host) */);
+int64_t agnn_sampler_edge_capacity(const agnn_sampler_t* cfg /* (host) */);
+int agnn_sample_hops(const agnn_sampler_t* cfg /* (host) */, agnn_stream_t stream);
+int agnn_gather_rows_f32(const float* src, int64_t ld_src, const int32_t* gid, int64_t n, int32_t H, float* out,
+                         int64_t ld_out, agnn_stream_t stream);
+int agnn_gather_i64(const int64_t* src, int64_t ld_src, const int32_t* gid, int64_t n, int32_t n_vec, int64_t fill,
+                    int64_t* out, int64_t ld_out, agnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Per-head relation transforms of HGTConv (PyG `k_rel` / `v_rel`: one D x D matrix per (edge type, head); reached through

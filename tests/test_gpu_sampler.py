@@ -1,0 +1,176 @@
+"""Device-side batch assembly (csrc/sampler.hip, analysisgnn_amd/batching.py) against oracle/sampler_ref.py: node ids and
+edge slots bit for bit; the padded static-shape batch gives the model the same target rows as the compact batch; the
+whole sampled step replays from ONE captured hipGraph with a different batch per replay."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import assert_close  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def _store(n_scores=4, n_notes=800, tasks=None):
+    from analysisgnn_amd.batching import ScoreStore
+    from analysisgnn_amd.synth import make_score_graph
+    graphs = [make_score_graph(seed=60 + i, n_notes=n_notes) for i in range(n_scores)]
+    return ScoreStore(graphs, 25, DEV, tasks=tasks or {"cadence": 4, "localkey": 50}, seed=3), graphs
+
+
+@pytest.mark.parametrize("fan,cap,T", [((5, 5), (64, 64), 500), ((1, 2), (128, 96), 200), ((3,), (32,), 64)])
+def test_sampler_matches_oracle_bit_for_bit(fan, cap, T):
+    from analysisgnn_amd import _lib
+    from analysisgnn_amd.batching import DeviceSampler
+    from oracle import sampler_ref as S
+    store, _ = _store()
+    B = 6
+    smp = DeviceSampler(store, B, T, fan, cap, seed=11)
+    rng = np.random.default_rng(1)
+    rowptr = [c.rowptr.cpu().numpy() for c in store.csr]
+    base = rowptr[0][0]
+    col = [c.col.cpu().numpy() for c in store.csr]
+    for step in (1, 2):
+        wins = store.random_windows(B, T, rng)
+        smp.set_windows(wins)
+        batch = smp.sample()
+        torch.cuda.synchronize()
+        # the store's CSR segments index one shared col array: rebase rowptr for the oracle
+        gid, edges, dropped = S.sample_hops([rp - 0 for rp in rowptr], col, wins, T, fan, cap, seed=11, step=step)
+        assert np.array_equal(smp.node_gid.cpu().numpy(), gid)
+        for r, et in enumerate(store.edge_types):
+            assert np.array_equal(batch["edge_index_dict"][et].cpu().numpy(), edges[r]), et
+        # gathered attributes: features, spelling / key, labels of the targets
+        g = torch.from_numpy(gid.astype(np.int64)).to(DEV)
+        real = g >= 0
+        assert torch.equal(smp.x[real], store.x[g[real]]) and float(smp.x[~real].abs().sum()) == 0.0
+        assert torch.equal(batch["pitch_spelling"][real], store.attrs[0][g[real]])
+        assert torch.equal(batch["label_matrix"], store.attrs[2:, g[:B * T]])
+    _lib.check_device_status(DEV)                                   # no capacity overflow at these capacities
+
+
+def test_capacity_overflow_is_reported():
+    from analysisgnn_amd import _lib
+    from analysisgnn_amd.batching import DeviceSampler
+    store, _ = _store()
+    word = _lib.status_word(DEV)
+    before = int(word.item())
+    smp = DeviceSampler(store, 2, 100, (5, 5), (4, 4), seed=1)
+    smp.set_windows(np.array([300, 1200], dtype=np.int32))
+    smp.sample()
+    torch.cuda.synchronize()
+    assert int(word.item()) > before
+    with pytest.raises(_lib.AgnnError):
+        _lib.check_device_status(DEV)
+    word.zero_()                                                    # leave the shared word clean for the other tests
+
+
+def test_padded_batch_equals_compact_batch_on_the_model():
+    """Same sampled subgraphs, once as the padded static-shape batch the sampler writes and once compacted the way a
+    NeighborLoader would hand them over (padding slots and (-1, -1) edges removed, per-hop counts = the real counts):
+    the target rows of the encoder output agree to rounding.  Checked against the CPU restatement too."""
+    from analysisgnn_amd.batching import DeviceSampler
+    from analysisgnn_amd.encoders import HybridGNN
+    from oracle import encoders_ref as E
+    store, _ = _store(tasks={"a": 3})
+    B, T, H = 3, 200, 32
+    smp = DeviceSampler(store, B, T, (5, 5), (48, 48), seed=2)
+    smp.set_windows(store.random_windows(B, T, np.random.default_rng(4)))
+    batch = smp.sample()
+    torch.cuda.synchronize()
+    md = (["note"], store.edge_types)
+    torch.manual_seed(0)
+    m = HybridGNN(metadata=md, input_channels=H, hidden_channels=H, num_layers=3, dropout=0.0).eval()
+    P = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV)
+    gen = torch.Generator().manual_seed(5)
+    feat = torch.randn(store.num_notes, H, generator=gen)
+    gid = smp.node_gid.cpu().long()
+    x = torch.where((gid >= 0).unsqueeze(1), feat[gid.clamp(min=0)], torch.zeros(1, H))
+    with torch.no_grad():
+        out = m(x_dict={"note": x.to(DEV)}, edge_index_dict=batch["edge_index_dict"], batch_dict=batch["batch_dict"],
+                batch_size=smp.batch_size, neighbor_mask_node=batch["neighbor_mask_node"], neighbor_mask_edge=batch["neighbor_mask_edge"])
+    # compact form for the CPU path
+    keep = gid >= 0
+    new_id = torch.cumsum(keep.long(), 0) - 1
+    blocks = smp.num_sampled_nodes["note"]
+    nb = np.concatenate([[0], np.cumsum(blocks)])
+    nodes_per_hop = [int(keep[nb[h]:nb[h + 1]].sum()) for h in range(len(blocks))]
+    ei_c, edges_per_hop = {}, {}
+    for et, e in batch["edge_index_dict"].items():
+        e = e.cpu()
+        counts, parts, lo = [], [], 0
+        for eh in smp.num_sampled_edges[et]:
+            seg = e[:, lo:lo + eh]
+            seg = seg[:, seg[0] >= 0]
+            parts.append(new_id[seg])
+            counts.append(int(seg.shape[1]))
+            lo += eh
+        ei_c[et], edges_per_hop[et] = torch.cat(parts, dim=1), counts
+    xc = x[keep]
+    bc = batch["batch_dict"]["note"].cpu()[keep]
+    with torch.no_grad():
+        ref = E.hybrid_gnn(P, "", md, 3, {"note": xc}, ei_c, {"note": bc}, smp.batch_size, {"note": nodes_per_hop}, edges_per_hop)
+    assert_close(out, ref, 1e-4, "padded batch vs compact batch")
+
+
+def test_sampled_step_replays_from_one_graph_with_a_fresh_batch_each_time():
+    """sample -> gather -> CSR build -> forward -> objective -> backward captured ONCE; every replay runs on other windows and
+    another random step and must give the loss / gradients of the same batch run eagerly."""
+    from analysisgnn_amd import dp, graph
+    from analysisgnn_amd.batching import DeviceSampler
+    from analysisgnn_amd.heads import training_loss
+    from analysisgnn_amd.models import TorchAnalysisGNN
+    tasks = {"cadence": 4, "localkey": 50, "romanNumeral": 185}
+    store, _ = _store(n_scores=5, n_notes=900, tasks=tasks)
+    B, T = 4, 500
+    smp = DeviceSampler(store, B, T, (5, 5), (64, 64), seed=9)
+    md = (["note"], store.edge_types)
+    torch.manual_seed(0)
+    model = TorchAnalysisGNN(md, 25, 256, 128, tasks, 3, dropout=0.0, use_jk=False, logit_fusion=False).to(DEV).train()
+    params, tight = dp.plan_parameters(model)
+    flat = dp.FlatGradBuffer(params, views=False, tight=tight)
+    was = graph.index_cache_enabled
+    graph.index_cache_enabled = False
+    dp.enable_wgrad_overlap(False)
+    rng = np.random.default_rng(8)
+    try:
+        def step(resample=True):
+            flat.zero()
+            b = smp.sample() if resample else smp.batch
+            x = model.encode(b["pitch_spelling"], b["key_signature"], b["x_dict"], b["edge_index_dict"], b["batch_dict"], b["batch_size"],
+                             b["neighbor_mask_node"], b["neighbor_mask_edge"])
+            logits, offs, _ = model.forward_clf_fused(x)
+            loss, _ = training_loss(logits, offs, b["label_matrix"], x, 0.1, 0.1, -1)
+            loss.backward()
+            flat.pack()
+            return loss
+
+        smp.set_windows(store.random_windows(B, T, rng))
+        side = torch.cuda.Stream(device=DEV)
+        side.wait_stream(torch.cuda.current_stream(DEV))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream(DEV).wait_stream(side)
+        torch.cuda.synchronize()
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
+            loss_g = step()
+        losses = []
+        for it in range(3):
+            smp.set_windows(store.random_windows(B, T, rng))
+            cg.replay()
+            torch.cuda.synchronize()
+            g_graph, l_graph = flat.flat.clone(), float(loss_g)
+            gid_graph = smp.node_gid.clone()
+            l_eager = float(step(resample=False))                   # the same batch (buffers as the replay left them), eagerly
+            torch.cuda.synchronize()
+            assert torch.equal(smp.node_gid, gid_graph)
+            assert l_graph == l_eager
+            assert torch.equal(flat.flat, g_graph)
+            losses.append(l_graph)
+        assert len(set(losses)) == 3                                # three different batches
+    finally:
+        graph.index_cache_enabled = was

@@ -1,0 +1,96 @@
+"""The batch sampler's contract on the CPU restatement (oracle/sampler_ref.py): the invariants the reference's consumers
+rely on (PyG NeighborLoader layout consumed at models/analysis.py:948-961 and by trim_to_layer, models/cadence.py:165-173).
+The choice of neighbours itself is parity-unpinned (graphmuse's loader is not available); these are properties."""
+import numpy as np
+import pytest
+
+from analysisgnn_amd.synth import make_score_graph
+from oracle import sampler_ref as S
+
+
+def _store(n_scores=3, n_notes=700):
+    graphs = [make_score_graph(seed=40 + i, n_notes=n_notes) for i in range(n_scores)]
+    start = np.concatenate([[0], np.cumsum([n_notes] * n_scores)])
+    ets = graphs[0].edge_types
+    rowptr, col = [], []
+    for et in ets:
+        src = np.concatenate([g.edge_index[et][0] + o for g, o in zip(graphs, start[:-1])])
+        dst = np.concatenate([g.edge_index[et][1] + o for g, o in zip(graphs, start[:-1])])
+        order = np.lexsort((np.arange(dst.size), dst))                # stable by destination
+        rp = np.zeros(start[-1] + 1, dtype=np.int64)
+        np.add.at(rp, dst + 1, 1)
+        rowptr.append(np.cumsum(rp).astype(np.int32))
+        col.append(src[order].astype(np.int32))
+    return graphs, start, rowptr, col
+
+
+def test_philox_known_answer():
+    """Random123 known-answer vectors for Philox-4x32-10 (kat_vectors: counter / key all zeros, all ones, and the pi digits)."""
+    assert S.philox4x32_10((0, 0, 0, 0), (0, 0)) == (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)
+    assert S.philox4x32_10((0xffffffff,) * 4, (0xffffffff,) * 2) == (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)
+    assert S.philox4x32_10((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0)) == \
+        (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)
+
+
+@pytest.mark.parametrize("fan,cap", [((5, 5), (64, 64)), ((2, 3), (96, 128)), ((1,), (8,))])
+def test_layout_invariants(fan, cap):
+    graphs, start, rowptr, col = _store()
+    T, wins = 120, [50, 700 + 300, 1400 + 580]
+    gid, edges, dropped = S.sample_hops(rowptr, col, wins, T, fan, cap, seed=7, step=3)
+    B = len(wins)
+    blocks = [B * T] + [B * c for c in cap]
+    nb = np.concatenate([[0], np.cumsum(blocks)])
+    assert gid.size == nb[-1]
+    # targets are the windows; every node belongs to its window's score; no node twice inside a subgraph
+    for s, w in enumerate(wins):
+        assert (gid[s * T:(s + 1) * T] == np.arange(w, w + T)).all()
+        mine = [gid[s * T:(s + 1) * T]] + [gid[nb[h + 1] + s * cap[h]: nb[h + 1] + (s + 1) * cap[h]] for h in range(len(cap))]
+        allg = np.concatenate(mine)
+        real = allg[allg >= 0]
+        assert real.size == np.unique(real).size
+        sc = np.searchsorted(start, w, side="right") - 1
+        assert ((real >= start[sc]) & (real < start[sc + 1])).all()
+        for h in range(len(cap)):                      # a hop's new nodes: ascending global id, padding behind them
+            blk = mine[h + 1]
+            k = int((blk >= 0).sum())
+            assert (blk[:k] >= 0).all() and (blk[k:] == -1).all() and (np.diff(blk[:k]) > 0).all()
+    F, e0 = T, 0
+    for h in range(len(cap)):
+        eh = B * F * fan[h]
+        for r in range(len(edges)):
+            seg = edges[r][:, e0:e0 + eh]
+            live = seg[0] >= 0
+            assert ((seg[0] >= 0) == (seg[1] >= 0)).all()
+            # hop h+1 edges: target in hop block h, source in hop blocks <= h + 1 (what trim_to_layer assumes)
+            assert ((seg[1][live] >= nb[h]) & (seg[1][live] < nb[h + 1])).all()
+            assert (seg[0][live] < nb[h + 2]).all()
+            assert (gid[seg[0][live]] >= 0).all() and (gid[seg[1][live]] >= 0).all()
+            # the edge exists in the score graph, at most `fan` per (target, relation), none across subgraphs
+            et = graphs[0].edge_types[r]
+            for s_l, d_l in zip(seg[0][live][:200], seg[1][live][:200]):
+                gs, gd = int(gid[s_l]), int(gid[d_l])
+                st, en = rowptr[r][gd], rowptr[r][gd + 1]
+                assert gs in col[r][st:en]
+            cnt = np.bincount(seg[1][live], minlength=nb[-1])
+            assert cnt.max(initial=0) <= fan[h]
+        e0 += eh
+        F = cap[h]
+    assert e0 == edges[0].shape[1]
+
+
+def test_reproducible_and_step_dependent():
+    _, _, rowptr, col = _store()
+    a = S.sample_hops(rowptr, col, [10, 900], 100, (1, 1), (64, 64), seed=5, step=1)      # fan 1 forces the random branch
+    b = S.sample_hops(rowptr, col, [10, 900], 100, (1, 1), (64, 64), seed=5, step=1)
+    c = S.sample_hops(rowptr, col, [10, 900], 100, (1, 1), (64, 64), seed=5, step=2)
+    assert all((x == y).all() for x, y in zip(a[1], b[1])) and (a[0] == b[0]).all()
+    assert any((x != y).any() for x, y in zip(a[1], c[1]))
+
+
+def test_capacity_overflow_is_counted_not_silent():
+    _, _, rowptr, col = _store()
+    gid, edges, dropped = S.sample_hops(rowptr, col, [300], 100, (5, 5), (4, 4), seed=1, step=1)
+    assert dropped > 0
+    for e in edges:                                     # edges to dropped nodes are not emitted
+        live = e[0] >= 0
+        assert (gid[e[0][live]] >= 0).all()
