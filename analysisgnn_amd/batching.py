@@ -121,8 +121,16 @@ class DeviceSampler:
             label_matrix=self.attrs[2:, :self.batch_size])
 
     def set_windows(self, win_start: np.ndarray) -> None:
-        """The only per-batch host-to-device traffic: n_sub int32 (outside the captured graph, like any input refill)."""
-        self.win_start.copy_(torch.from_numpy(np.ascontiguousarray(win_start, dtype=np.int32)), non_blocking=True)
+        """The only per-batch host-to-device traffic: n_sub int32 (outside the captured graph, like any input refill).
+        Staged through a small ring of PINNED buffers: a copy from pageable memory makes the host wait for the stream, i.e.
+        for the previous step, and the host then cannot run ahead of the device any more."""
+        if not hasattr(self, "_ring"):
+            self._ring = [torch.empty(self.n_sub, dtype=torch.int32).pin_memory() for _ in range(16)]
+            self._ring_pos = 0
+        buf = self._ring[self._ring_pos]
+        self._ring_pos = (self._ring_pos + 1) % len(self._ring)
+        buf.numpy()[:] = win_start
+        self.win_start.copy_(buf, non_blocking=True)
 
     def sample(self) -> dict:
         """Advance the step counter, sample, gather features and attributes — four launches, graph-capturable."""

@@ -65,7 +65,9 @@ __device__ __forceinline__ int select_positions(int deg, int fan, uint32_t dst, 
 
 __device__ __forceinline__ uint32_t hslot(int gid) { return (static_cast<uint32_t>(gid) * 2654435761u) >> 22; }   // 10 bits
 
-__global__ __launch_bounds__(256) void k_sample_hops(SamplerArgs A) {
+constexpr int kThreads = 1024;    // one workgroup per subgraph: 16 waves walk the (frontier node, relation) items side by side
+
+__global__ __launch_bounds__(kThreads) void k_sample_hops(SamplerArgs A) {
   const agnn_sampler_t& c = A.c;
   __shared__ int hkey[kHash];
   __shared__ int hval[kHash];
@@ -77,8 +79,8 @@ __global__ __launch_bounds__(256) void k_sample_hops(SamplerArgs A) {
   const int w = c.win_start[s];
   const uint2 key = make_uint2(static_cast<uint32_t>(c.rng[0]), static_cast<uint32_t>(static_cast<uint64_t>(c.rng[0]) >> 32));
   const uint32_t step = static_cast<uint32_t>(c.rng[1]);
-  for (int i = tid; i < kHash; i += 256) { hkey[i] = kEmpty; hval[i] = -1; }
-  for (int i = tid; i < T; i += 256) c.node_gid[static_cast<int64_t>(s) * T + i] = w + i;
+  for (int i = tid; i < kHash; i += kThreads) { hkey[i] = kEmpty; hval[i] = -1; }
+  for (int i = tid; i < T; i += kThreads) c.node_gid[static_cast<int64_t>(s) * T + i] = w + i;
   if (tid == 0) n_drop = 0;
   __syncthreads();
 
@@ -89,10 +91,10 @@ __global__ __launch_bounds__(256) void k_sample_hops(SamplerArgs A) {
   for (int h = 0; h < c.n_hops; ++h) {
     const int fan = c.fan[h], cap = c.cap[h];
     if (tid == 0) n_new = 0;
-    for (int i = tid; i < kNewMax; i += 256) newl[i] = 0x7fffffff;
+    for (int i = tid; i < kNewMax; i += kThreads) newl[i] = 0x7fffffff;
     __syncthreads();
     // ---- A: the sampled sources that are neither in the window nor known yet
-    for (int it = tid; it < F * c.n_rel; it += 256) {
+    for (int it = tid; it < F * c.n_rel; it += kThreads) {
       const int i = it / c.n_rel, r = it - i * c.n_rel;
       const int dst = h == 0 ? w + i : fr_gid[i];
       const int st = c.rowptr[r][dst], deg = c.rowptr[r][dst + 1] - st;
@@ -115,9 +117,11 @@ __global__ __launch_bounds__(256) void k_sample_hops(SamplerArgs A) {
     }
     __syncthreads();
     // ---- B: ascending global id (bitonic sort of the padded list), the first `cap` get this hop's slots
-    for (int k2 = 2; k2 <= kNewMax; k2 <<= 1) {
+    int P = 2;                                              // sort only as many slots as there are candidates (usually a handful)
+    while (P < n_new && P < kNewMax) P <<= 1;
+    for (int k2 = 2; k2 <= P; k2 <<= 1) {
       for (int j = k2 >> 1; j > 0; j >>= 1) {
-        for (int i = tid; i < kNewMax; i += 256) {
+        for (int i = tid; i < P; i += kThreads) {
           const int ixj = i ^ j;
           if (ixj > i) {
             const int a = newl[i], b = newl[ixj];
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(256) void k_sample_hops(SamplerArgs A) {
     const int found = n_new < kNewMax ? n_new : kNewMax;
     const int kept = found < cap ? found : cap;
     if (tid == 0 && n_new > kept) n_drop += n_new - kept;
-    for (int i = tid; i < cap; i += 256) {
+    for (int i = tid; i < cap; i += kThreads) {
       const int g = i < kept ? newl[i] : -1;
       c.node_gid[nbase + static_cast<int64_t>(s) * cap + i] = g;
       if (i < kept) {
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(256) void k_sample_hops(SamplerArgs A) {
     }
     __syncthreads();
     // ---- C: the edges, every (frontier node, relation, k) in its own slot
-    for (int it = tid; it < Fcap * c.n_rel; it += 256) {
+    for (int it = tid; it < Fcap * c.n_rel; it += kThreads) {
       const int i = it / c.n_rel, r = it - i * c.n_rel;
       int64_t* e0 = c.edges[r] + ebase + (static_cast<int64_t>(s) * Fcap + i) * fan;
       int64_t* e1 = e0 + c.e_cap;
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256) void k_sample_hops(SamplerArgs A) {
     }
     __syncthreads();
     // ---- next frontier = this hop's new nodes, in slot order
-    for (int i = tid; i < cap; i += 256) fr_gid[i] = i < kept ? newl[i] : -1;
+    for (int i = tid; i < cap; i += kThreads) fr_gid[i] = i < kept ? newl[i] : -1;
     ebase += static_cast<int64_t>(c.n_sub) * Fcap * fan;
     fr_local0 = nbase + static_cast<int64_t>(s) * cap;
     nbase += static_cast<int64_t>(c.n_sub) * cap;
@@ -245,7 +249,7 @@ extern "C" int agnn_sample_hops(const agnn_sampler_t* cfg, agnn_stream_t stream_
   for (int r = 0; r < c.n_rel; ++r)
     if (!c.rowptr[r] || !c.col[r] || !c.edges[r]) return fail(AGNN_EINVAL, "sample_hops: relation %d incomplete", r);
   SamplerArgs A{c};
-  hipLaunchKernelGGL(k_sample_hops, dim3(static_cast<unsigned>(c.n_sub)), dim3(256), 0, static_cast<hipStream_t>(stream_), A);
+  hipLaunchKernelGGL(k_sample_hops, dim3(static_cast<unsigned>(c.n_sub)), dim3(kThreads), 0, static_cast<hipStream_t>(stream_), A);
   return check_launch("sample_hops");
 }
 

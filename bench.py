@@ -45,11 +45,15 @@ WORKLOADS = {
     "c2s": "C2 (sampled, the batch a training step sees): HybridGNN L=3 H=256 out=128, 21 task heads, 32 neighbour-sampled "
            "subgraphs x (500 target notes + [5,5] hops) per GPU, per-hop counts passed (every layer trimmed)",
     "c2": "C2 (whole graphs, no trimming): HybridGNN L=3 H=256 out=128, 21 task heads, 32 subgraphs x 500 notes per GPU",
+    "c2d": "C2 with the batch assembled ON THE DEVICE inside the timed step: 64 scores x 1500 notes resident in HBM, every step "
+           "samples 32 fresh windows x (500 target notes + [5,5] hops) into static-shape buffers (agnn_sample_hops), gathers their "
+           "features, rebuilds the CSR and trains on them; HybridGNN L=3 H=256 out=128, 21 task heads",
     "c3": "C3: HGT L=3 H=256 heads=4, note+beat+measure nodes, 6 relation types, 21 task heads, 32 subgraphs x 500 notes per GPU "
           "(whole graphs)",
     "c5": "C5: MetricalGNN L=4 H=512, heads cadence/localkey/romanNumeral, 32 subgraphs x 500 notes per GPU (whole graphs)",
 }
 METRICS = {"c2s": "subgraph-nodes/sec fwd+bwd, HybridGNN L=3 H=256", "c2": "subgraph-nodes/sec fwd+bwd, HybridGNN L=3 H=256",
+           "c2d": "subgraph-nodes/sec fwd+bwd, HybridGNN L=3 H=256",
            "c3": "subgraph-nodes/sec fwd+bwd, HGT L=3 H=256", "c5": "subgraph-nodes/sec fwd+bwd, MetricalGNN L=4 H=512"}
 
 
@@ -108,7 +112,7 @@ def build_workload(name: str, rank: int, world: int, n_sub: int = N_SUB):
     from analysisgnn_amd.dp import shard_units
     from analysisgnn_amd.synth import make_batch, make_sampled_batch
     seeds = shard_units(n_sub * world, rank, world)
-    if name == "c2s":
+    if name in ("c2s", "c2d"):                     # c2d's CPU baseline / shapes: the same kind of batch, assembled on the host
         g = make_sampled_batch(n_sub, N_NOTES, (5,) * (LAYERS - 1), seeds=seeds)      # train_analysisgnn.py:82,154
         return g, "hybridgnn", H, LAYERS, TASK_DICT
     if name == "c2":
@@ -218,8 +222,22 @@ def main():
     dev = torch.device("cuda", local)
 
     g, enc, hid, layers, tasks = build_workload(args.workload, rank, world)
-    I = torch_inputs(g, IN_CH, dev, seed=rank)
-    labels = make_labels(I["batch_size"], dev, 100 + rank, tasks)
+    sampler = None
+    if args.workload == "c2d":
+        import numpy as np
+        from analysisgnn_amd.batching import DeviceSampler, ScoreStore
+        from analysisgnn_amd.synth import make_score_graph
+        # the corpus (replicated on every rank, as a dataset would be): 64 synthetic scores of 1500 notes; ranks draw
+        # different windows (their own host generator), i.e. disjoint subgraphs of the global batch
+        store = ScoreStore([make_score_graph(seed=1000 + i, n_notes=1500) for i in range(64)], IN_CH, dev, tasks=tasks, seed=0)
+        sampler = DeviceSampler(store, N_SUB, N_NOTES, (5,) * (layers - 1), (32,) * (layers - 1), seed=1 + rank)
+        win_rng = np.random.default_rng(100 + rank)
+        sampler.set_windows(store.random_windows(N_SUB, N_NOTES, win_rng))
+        I = sampler.sample()
+        labels = I["labels"]
+    else:
+        I = torch_inputs(g, IN_CH, dev, seed=rank)
+        labels = make_labels(I["batch_size"], dev, 100 + rank, tasks)
     torch.manual_seed(0)                                            # identical replicas
     model = TorchAnalysisGNN(g.metadata(), IN_CH, hid, OUT, tasks, layers, dropout=0.3, use_jk=False, logit_fusion=False,
                              encoder_type=enc).to(dev).train()
@@ -234,11 +252,13 @@ def main():
     opt = dp.FlatAdamW(params, flat, lr=5e-3, weight_decay=5e-3)     # analysis.py:1380-1381 hyper-parameters
     graph.index_cache_enabled = False                               # fresh batch every step: rebuild the CSR
 
-    label_mat = torch.stack([labels[t] for t in tasks])             # [T, N]
+    label_mat = I["label_matrix"] if sampler is not None else torch.stack([labels[t] for t in tasks])      # [T, N]
     one = torch.ones((), dtype=torch.float32, device=dev)
 
     def fwd_bwd():
         flat.zero()
+        if sampler is not None:
+            sampler.sample()                                        # this step's batch: sampled and gathered on the device
         x = model.encode(I["pitch_spelling"], I["key_signature"], I["x_dict"], I["edge_index_dict"], I["batch_dict"],
                          I["batch_size"], I["neighbor_mask_node"], I["neighbor_mask_edge"])      # analysis.py:953-961
         logits, offs, _ = model.forward_clf_fused(x)
@@ -277,6 +297,8 @@ def main():
             torch.cuda.synchronize(dev)
 
     def step():
+        if sampler is not None:                                     # the loader's only host-side decision: which windows (32 int32 H2D)
+            sampler.set_windows(store.random_windows(N_SUB, N_NOTES, win_rng))
         if graphs is not None:
             graphs[0].replay()
             flat.all_reduce_mean()
@@ -300,10 +322,13 @@ def main():
     from analysisgnn_amd import _lib
     _lib.check_device_status(dev)                      # no CSR build of the run flagged an inconsistent index (outside the timed region)
 
+    if sampler is not None:                                         # the roofline launch runs on the LAST sampled batch
+        g.edge_index = {et: e.cpu().numpy() for et, e in I["edge_index_dict"].items()}
+        g.num_nodes = {"note": sampler.num_nodes}
     roof = roofline(args.workload, g, I, hid, layers, dev) if rank == 0 else None
     if rank == 0:
         nodes = I["batch_size"] * world * args.steps
-        e_tot = sum(int(e.shape[1]) for e in g.edge_index.values())
+        e_tot = sum(int((e[0] >= 0).sum()) for e in g.edge_index.values())
         out = {
             "metric": METRICS[args.workload], "value": nodes / dt, "unit": "subgraph-nodes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -312,21 +337,26 @@ def main():
                                    f"objective ({args.mt_strategy}) + bwd + allreduce + clip + AdamW, CSR rebuilt every step; "
                                    + ("hipGraph replay" if graphs is not None else "eager launches"),
                        "workload_id": args.workload, "per_gpu_subgraphs": N_SUB, "target_notes_per_subgraph": N_NOTES,
-                       "objective": args.mt_strategy, "sharding": "rank r takes subgraphs {i : i mod G = r}",
+                       "objective": args.mt_strategy,
+                       "sharding": ("every rank draws its own windows from the replicated corpus" if args.workload == "c2d"
+                                    else "rank r takes subgraphs {i : i mod G = r}"),
                        "parallelism": f"dp{world}"},
             "roofline": roof,
         }
         if world == 1 and args.workload == "c2s" and not args.no_other:
-            # continuity with round 1's line (whole graphs, nothing trimmed): a child process, same steps
-            try:
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "c2", "--no-cpu-baseline", "--steps",
-                                    str(args.steps), "--warmup", str(args.warmup), "--mt-strategy", args.mt_strategy],
-                                   capture_output=True, text=True, timeout=300)
-                o = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-                out["other_workloads"] = {"c2": {"value": o["value"], "ms_per_step": o["ms_per_step"], "workload": o["config"]["workload"],
-                                                 "roofline": o["roofline"]}}
-            except Exception as e:                              # secondary figure only
-                out["other_workloads"] = {"c2": f"not measured ({type(e).__name__})"}
+            # secondary figures, each a child process with the same steps: "c2" = continuity with round 1's line (whole graphs,
+            # nothing trimmed); "c2d" = the same training step with the batch sampled and gathered ON THE DEVICE inside it
+            out["other_workloads"] = {}
+            for wl in ("c2", "c2d"):
+                try:
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", wl, "--no-cpu-baseline", "--steps",
+                                        str(args.steps), "--warmup", str(args.warmup), "--mt-strategy", args.mt_strategy],
+                                       capture_output=True, text=True, timeout=300)
+                    o = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                    out["other_workloads"][wl] = {"value": o["value"], "ms_per_step": o["ms_per_step"], "workload": o["config"]["workload"],
+                                                  "roofline": o["roofline"]}
+                except Exception as e:                              # secondary figures only
+                    out["other_workloads"][wl] = f"not measured ({type(e).__name__})"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.mt_strategy)
         print(json.dumps(out))
@@ -375,7 +405,7 @@ def roofline(workload, g, I, hid, layers, dev):
     hix = HeteroIndex(I["edge_index_dict"], n_nodes)
     ets = [et for et in hix.edge_types if et[0] == "note" and et[2] == "note"]
     plan = TrimPlan(layers, I["x_dict"], I["edge_index_dict"], I["neighbor_mask_node"], I["neighbor_mask_edge"])
-    layer = 1 if workload == "c2s" else 0                  # c2s: the first TRIMMED layer (rowend path), otherwise layer 0
+    layer = 1 if workload in ("c2s", "c2d") else 0         # sampled batches: the first TRIMMED layer (rowend path), otherwise layer 0
     hix.prepare_trim(plan.e_keep)
     n_dst = plan.n_keep[layer]["note"]
     e_keep = [plan.e_keep[layer][et] for et in ets]
@@ -389,7 +419,7 @@ def roofline(workload, g, I, hid, layers, dev):
     idx_bytes, e_kept, srcs = 0, 0, []
     for et, k in zip(ets, e_keep):
         ei = g.edge_index[et][:, :k] if k is not None else g.edge_index[et]
-        ei = ei[:, ei[1] < n_dst]
+        ei = ei[:, (ei[1] < n_dst) & (ei[0] >= 0)]         # (-1, -1): padding slots of a device-sampled batch
         idx_bytes += 4 * (n_dst + 1) + 4 * ei.shape[1]
         e_kept += int(ei.shape[1])
         srcs.append(ei[0])
