@@ -102,6 +102,11 @@ class TorchAnalysisGNN(nn.Module):
                     groups.append([getattr(rnn, f"{n}_l{layer}"), getattr(rnn, f"{n}_l{layer}_reverse")])
         return groups
 
+    # `torch.compile(model, dynamic=True)` (reference train/train_analysisgnn.py:202-203): the hot path is hand-written
+    # kernels behind ctypes calls inside autograd.Functions — nothing for a tracing compiler to fuse, and nothing it can trace
+    # through.  The three entry points are excluded from tracing as a whole, so a compiled wrapper runs this code unchanged
+    # (one clean graph break at the boundary instead of one per kernel call).
+    @torch._dynamo.disable
     def encode(self, pitch_spelling, key_signature, x_dict, edge_index_dict, batch_dict, batch_size,
                neighbor_mask_node, neighbor_mask_edge):
         if self.training:
@@ -118,12 +123,14 @@ class TorchAnalysisGNN(nn.Module):
         x = onset_pool(x, edge_index_dict[("note", "onset", "note")], batch_size, index)
         return self.project_enc(x)
 
+    @torch._dynamo.disable
     def forward_clf(self, x, tasks=None):
         """Same dict of logits as analysis.py:546-548, computed by the fused head schedule (heads.py);
         the values are column views of one [N, sum C] matrix."""
         logits, offs, tasks = self.forward_clf_fused(x, tasks)
         return {t: logits[:, offs[i]:offs[i + 1]] for i, t in enumerate(tasks)}
 
+    @torch._dynamo.disable
     def forward_clf_fused(self, x, tasks=None):
         tasks = list(self.clf_dict.keys() if tasks is None else tasks)
         logits, offs = fused_head_logits(self.clf_dict, x, tasks)

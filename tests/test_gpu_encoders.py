@@ -167,3 +167,24 @@ def test_module_obligations():
         m.cpu()(**{**kw, "x_dict": {k: v.cpu() for k, v in I["x_dict"].items()},
                    "edge_index_dict": {k: v.cpu() for k, v in I["edge_index_dict"].items()},
                    "batch_dict": {k: v.cpu() for k, v in I["batch_dict"].items()}})   # no CPU fallback
+
+
+def test_torch_compile_wrapping_runs_the_same_path():
+    """`torch.compile(model, dynamic=True)` as the reference's --compile flag does (train/train_analysisgnn.py:202-203): the
+    model's entry points are excluded from tracing, so the compiled module runs the HIP path unchanged — same logits,
+    gradients flow."""
+    from analysisgnn_amd.models import TorchAnalysisGNN
+    from analysisgnn_amd.synth import make_batch, torch_inputs
+    g = make_batch(2, 60)
+    tasks = {"cadence": 4, "localkey": 50}
+    torch.manual_seed(0)
+    m = TorchAnalysisGNN(g.metadata(), 25, 32, 128, tasks, 2, dropout=0.0, use_jk=False, logit_fusion=True).to(DEV).train()
+    I = torch_inputs(g, 25, DEV, 0)
+    args = (I["pitch_spelling"], I["key_signature"], I["x_dict"], I["edge_index_dict"], I["batch_dict"], I["batch_size"], None, None)
+    ref = m(*args)
+    cm = torch.compile(m, dynamic=True)
+    out = cm(*args)
+    for t in tasks:
+        assert torch.equal(out[t], ref[t])
+    sum(v.pow(2).mean() for v in out.values()).backward()
+    assert all(p.grad is not None for n, p in m.named_parameters() if n.startswith("clf_dict"))
