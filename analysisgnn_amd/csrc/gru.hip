@@ -272,7 +272,38 @@ __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, co
   if (s < T) { phaseA(s, inA); lds_barrier(); phaseB(); lds_barrier(); }
 }
 
+// h_{t-1} of both directions as one [B*T, 2*HH] matrix — the left operand of the W_hh weight-gradient GEMMs:
+// forward half = y[b, t-1, :HH] (zero at t = 0), reverse half = y[b, t+1, HH:] (zero at t = T-1).  One pass, 16-byte lanes.
+__global__ __launch_bounds__(256) void k_gru_hprev(const float* __restrict__ y, int T, int64_t total4, float* __restrict__ hp) {
+  constexpr int Q = 2 * HH / 4;          // float4 per row
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < total4; e += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t row = e / Q;
+    const int q = static_cast<int>(e - row * Q);
+    const int t = static_cast<int>(row % T);
+    const bool rev = q >= Q / 2;
+    const bool has = rev ? (t + 1 < T) : (t > 0);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has) v = reinterpret_cast<const float4*>(y)[(rev ? row + 1 : row - 1) * Q + q];
+    reinterpret_cast<float4*>(hp)[e] = v;
+  }
+}
+
 }  // namespace
+
+extern "C" int agnn_gru_hprev_f32(const float* y, int64_t B, int64_t T, int32_t hidden, float* hp, agnn_stream_t stream_) {
+  using namespace agnn;
+  if (hidden != HH) return fail(AGNN_EINVAL, "gru_hprev: hidden=%d unsupported (this build: %d)", hidden, HH);
+  if (B < 0 || T < 0 || T >= (int64_t{1} << 31)) return fail(AGNN_EINVAL, "gru_hprev: bad B=%lld T=%lld", (long long)B, (long long)T);
+  if (B == 0 || T == 0) return AGNN_OK;
+  if (!y || !hp) return fail(AGNN_EINVAL, "gru_hprev: null argument");
+  if (!aligned16(y) || !aligned16(hp)) return fail(AGNN_EALIGN, "gru_hprev: pointers must be 16-byte aligned");
+  const int64_t total4 = B * T * (2 * HH / 4);
+  int64_t blocks = (total4 + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_gru_hprev, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream_), y,
+                     static_cast<int>(T), total4, hp);
+  return check_launch("gru_hprev");
+}
 
 extern "C" int agnn_gru_fwd_f32(const float* gi, const float* w_hh, const float* b_hh, int64_t B, int64_t T,
                                 int32_t hidden, float* y, float* saved, agnn_stream_t stream_) {

@@ -262,8 +262,18 @@ __global__ __launch_bounds__(1024) void k_na_colsum(const float* __restrict__ pa
   const int j = blockIdx.x * 32 + col;
   float s = 0.f;
   if (j < width) {
-#pragma unroll 8
-    for (int w = grp; w < n_rows; w += 32) s += part[static_cast<int64_t>(w) * width + j];
+    // all 32 loads of a pass are in flight together (the slab has just been written: L2 / MALL hits); a chain of
+    // 8-at-a-time loads made this launch four memory round trips long
+    for (int w0 = grp; w0 < n_rows; w0 += 32 * 32) {
+      float v[32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        const int w = w0 + 32 * k;
+        v[k] = w < n_rows ? part[static_cast<int64_t>(w) * width + j] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 32; ++k) s += v[k];
+    }
   }
   sm[grp][col] = s;
   __syncthreads();

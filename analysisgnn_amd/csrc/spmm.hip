@@ -32,6 +32,7 @@ struct SpmmArgs {
   float* inv_cnt;
   int32_t col_limit;
   uint32_t flags;
+  int32_t self_rows;   // rows of `self`; rows beyond take no self term (AGNN_SPMM_ROOT: the root slot may be shorter than the output)
 };
 
 __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -368,11 +369,16 @@ __global__ __launch_bounds__(256) void k_spmm_fast7(FastTable t, SpmmArgs a) {
   const bool skip_self = FILT && (a.flags & AGNN_SPMM_SKIP_SELF) != 0;
   const uint32_t loff = static_cast<uint32_t>(lane) * 16u;
 
+  // `self` is either the torch_scatter numerator term (added to every relation before the scale) or, with AGNN_SPMM_ROOT,
+  // the root operand of a SAGE layer: an extra output slot behind the relations' (forward) / one more addend of the
+  // shared sum for the rows it has (backward).  Uniform per launch: a scalar branch.
+  const bool root = SELF && (a.flags & AGNN_SPMM_ROOT) != 0;
   float4 selfv[SELF ? CH : 1];
   if (SELF) {
-    const char* sp = reinterpret_cast<const char*>(a.self + static_cast<int64_t>(row) * a.ld_self);
+    const bool has = row < a.self_rows;
+    const char* sp = reinterpret_cast<const char*>(a.self + static_cast<int64_t>(has ? row : 0) * a.ld_self);
 #pragma unroll
-    for (int c = 0; c < (SELF ? CH : 1); ++c) selfv[c] = *reinterpret_cast<const float4*>(sp + (loff + c * 1024u));
+    for (int c = 0; c < (SELF ? CH : 1); ++c) selfv[c] = f4_keep(has, *reinterpret_cast<const float4*>(sp + (loff + c * 1024u)));
   }
   float4 tot[SHARED ? CH : 1];
 #pragma unroll
@@ -568,7 +574,7 @@ __global__ __launch_bounds__(256) void k_spmm_fast7(FastTable t, SpmmArgs a) {
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
         float4& o = v0[u][c];
-        if (SELF) f4_add(o, selfv[SELF ? c : 0]);
+        if (SELF && !root) f4_add(o, selfv[SELF ? c : 0]);
         o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
       }
       if (SHARED) {
@@ -586,7 +592,15 @@ __global__ __launch_bounds__(256) void k_spmm_fast7(FastTable t, SpmmArgs a) {
   if (SHARED) {
     char* op = reinterpret_cast<char*>(a.out + static_cast<int64_t>(row) * a.ld_out);
 #pragma unroll
-    for (int c = 0; c < CH; ++c) *reinterpret_cast<float4*>(op + (loff + c * 1024u)) = tot[SHARED ? c : 0];
+    for (int c = 0; c < CH; ++c) {
+      float4 o = tot[SHARED ? c : 0];
+      if (root) f4_add(o, selfv[SELF ? c : 0]);
+      *reinterpret_cast<float4*>(op + (loff + c * 1024u)) = o;
+    }
+  } else if (root) {
+    char* op = reinterpret_cast<char*>(a.out + static_cast<int64_t>(row) * a.ld_out + static_cast<int64_t>(t.n_rel) * a.rel_stride);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) *reinterpret_cast<float4*>(op + (loff + c * 1024u)) = selfv[SELF ? c : 0];
   }
 }
 
@@ -676,9 +690,38 @@ extern "C" int agnn_spmm_self_grad_f32(const float* dout, int64_t ld_dout, int64
   return check_launch("spmm_self_grad");
 }
 
+namespace {
+int spmm_entry(int n_rel, const agnn_rel_t* rels, int64_t n_rows, int32_t H, float* out, int64_t ld_out, int64_t rel_stride,
+               const float* self, int64_t ld_self, int64_t self_rows, float* inv_cnt, int32_t col_limit, uint32_t flags,
+               agnn_stream_t stream_);
+}
+
 extern "C" int agnn_spmm_f32(int n_rel, const agnn_rel_t* rels, int64_t n_rows, int32_t H, float* out,
                              int64_t ld_out, int64_t rel_stride, const float* self, int64_t ld_self,
                              float* inv_cnt, int32_t col_limit, uint32_t flags, agnn_stream_t stream_) {
+  if (flags & AGNN_SPMM_ROOT) return agnn::fail(AGNN_EINVAL, "spmm: AGNN_SPMM_ROOT is agnn_spmm_root_f32's flag");
+  return spmm_entry(n_rel, rels, n_rows, H, out, ld_out, rel_stride, self, ld_self, n_rows, inv_cnt, col_limit, flags, stream_);
+}
+
+extern "C" int agnn_spmm_root_f32(int n_rel, const agnn_rel_t* rels, int64_t n_rows, int32_t H, float* out, int64_t ld_out,
+                                  int64_t rel_stride, const float* root, int64_t ld_root, int64_t root_rows, float* inv_cnt,
+                                  int32_t col_limit, uint32_t flags, agnn_stream_t stream_) {
+  using namespace agnn;
+  if (!root || root_rows < 0) return fail(AGNN_EINVAL, "spmm_root: null root operand or root_rows=%lld", (long long)root_rows);
+  if (rel_stride != 0 && root_rows < n_rows) return fail(AGNN_EINVAL, "spmm_root: the root slot needs a row per output row (root_rows=%lld < n_rows=%lld)", (long long)root_rows, (long long)n_rows);
+  if (flags & (AGNN_SPMM_ACCUM | AGNN_SPMM_GENERIC | AGNN_SPMM_FAST_V4)) return fail(AGNN_EINVAL, "spmm_root: flags 0x%x not supported", flags);
+  if (H != 256 && H != 512) return fail(AGNN_EINVAL, "spmm_root: H=%d (256 or 512: the widths the specialised kernel is built for)", H);
+  if (rel_stride != 0 && ld_out < n_rel * rel_stride + H) return fail(AGNN_EINVAL, "spmm_root: ld_out=%lld has no room for the root slot", (long long)ld_out);
+  for (int r = 0; rels && r < n_rel && r < AGNN_MAX_SEG; ++r)
+    if (rels[r].ew != nullptr) return fail(AGNN_EINVAL, "spmm_root: per-edge weights are not supported");
+  return spmm_entry(n_rel, rels, n_rows, H, out, ld_out, rel_stride, root, ld_root, root_rows < n_rows ? root_rows : n_rows, inv_cnt,
+                    col_limit, flags | AGNN_SPMM_ROOT, stream_);
+}
+
+namespace {
+int spmm_entry(int n_rel, const agnn_rel_t* rels, int64_t n_rows, int32_t H, float* out, int64_t ld_out, int64_t rel_stride,
+               const float* self, int64_t ld_self, int64_t self_rows, float* inv_cnt, int32_t col_limit, uint32_t flags,
+               agnn_stream_t stream_) {
   using namespace agnn;
   if (n_rel <= 0 || n_rel > AGNN_MAX_SEG) return fail(AGNN_EINVAL, "spmm: n_rel=%d not in [1,%d]", n_rel, AGNN_MAX_SEG);
   if (n_rows < 0 || n_rows >= (int64_t{1} << 31)) return fail(AGNN_EINVAL, "spmm: n_rows=%lld", (long long)n_rows);
@@ -695,7 +738,7 @@ extern "C" int agnn_spmm_f32(int n_rel, const agnn_rel_t* rels, int64_t n_rows, 
     if (rels[r].src && (!aligned16(rels[r].src) || (rels[r].ld_src & 3) || rels[r].ld_src < H)) return fail(AGNN_EALIGN, "spmm: relation %d src misaligned or ld_src < H", r);
     t.r[r] = rels[r];
   }
-  SpmmArgs a{static_cast<int32_t>(n_rows), H, out, ld_out, rel_stride, self, ld_self, inv_cnt, col_limit, flags};
+  SpmmArgs a{static_cast<int32_t>(n_rows), H, out, ld_out, rel_stride, self, ld_self, inv_cnt, col_limit, flags, static_cast<int32_t>(self_rows)};
   int64_t blocks = ((n_rows + 3) / 4 + 7) & ~int64_t{7};   // multiple of 8: the XCD remap is a bijection
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (!(flags & AGNN_SPMM_GENERIC) && (H == 256 || H == 512)) {
@@ -716,8 +759,10 @@ extern "C" int agnn_spmm_f32(int n_rel, const agnn_rel_t* rels, int64_t n_rows, 
       return check_launch("spmm(fast)");
     }
   }
+  if (flags & AGNN_SPMM_ROOT) return fail(AGNN_EINVAL, "spmm_root: this launch is outside the specialised kernel (missing src / col, or mixed column scales)");
   if (H <= 256) launch_s<1>(dim3(blocks), stream, t, a);
   else if (H <= 512) launch_s<2>(dim3(blocks), stream, t, a);
   else launch_s<4>(dim3(blocks), stream, t, a);
   return check_launch("spmm");
 }
+}  // namespace

@@ -107,6 +107,8 @@ class FlatGradBuffer:
                 raise ValueError("FlatGradBuffer: fp32 parameters on one device expected")
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self._pad = torch.zeros(4, dtype=torch.float32, device=dev)
+        # a parameter that took no gradient this step (a layer that keeps no edge: encoders.HeteroConv) packs from here
+        self._none = torch.zeros(max(self.sizes) if self.sizes else 1, dtype=torch.float32, device=dev)
         if views:
             self._assign_views()
 
@@ -132,7 +134,7 @@ class FlatGradBuffer:
         self._packed = True
         parts = []
         for p, k, o, o_next in zip(self.params, self.sizes, self.offsets, self.offsets[1:]):
-            parts.append((p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1))
+            parts.append(p.grad.reshape(-1) if p.grad is not None else self._none[:k])
             if o_next - o > k:
                 parts.append(self._pad[: o_next - o - k])
         torch.cat(parts, out=self.flat)

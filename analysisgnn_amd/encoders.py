@@ -32,7 +32,7 @@ import torch.nn.functional as F
 from . import _lib, ops
 from .gru import gru_forward
 from .fused import FusedSequential, norm_act
-from .params import sage_operands
+from .params import sage_operands, sage_operands_cat
 from .linear import Linear, linear
 from .core_layers import JumpingKnowledge
 from .graph import HeteroIndex, hetero_index
@@ -139,9 +139,26 @@ class HeteroConv(nn.Module):
                     src_types.append(et[0])
                 src_id.append(src_types.index(et[0]))
             convs = [self.convs[et_key(et)] for et in ets]
-            W_l, b, W_r = sage_operands([c.lin_l.weight for c in convs], [c.lin_l.bias for c in convs],
-                                        [c.lin_r.weight for c in convs])                 # [out, R*H], [out], [out, H]
-            if e_keep is not None and all(e_keep[et] is not None and e_keep[et] <= 0 for et in ets):
+            plist = ([c.lin_l.weight for c in convs], [c.lin_l.bias for c in convs], [c.lin_r.weight for c in convs])
+            no_edges = e_keep is not None and all(e_keep[et] is not None and e_keep[et] <= 0 for et in ets)
+            # One GEMM per layer where the kernel carries the root operand along (agnn_spmm_root_f32: widths 256 / 512):
+            # y = [mean_1 .. mean_R | x_dst] @ [W_l_1 .. W_l_R | sum_r W_r_r]^T + sum_r b_r
+            fused = (no_edges or self.in_channels in ops.ROOT_WIDTHS) and x_dict[d].is_cuda
+            cat = sage_operands_cat(*plist, with_l=not no_edges) if fused else None
+            if cat is not None and no_edges:
+                y = linear(_head(x_dict[d], n), cat[0], cat[1])           # see below: lin_l contributes its bias only
+                out[d] = y / len(ets) if self.aggr == "mean" else y
+                continue
+            if cat is not None:
+                spec = ops.AggSpec(fwd=[index.fwd[et] for et in ets], bwd=[index.bwd[et] for et in ets], src_id=src_id,
+                                   n_rows=n, mean=True, shared_slot=False, root=True,
+                                   e_limit=[e_keep[et] for et in ets] if e_keep is not None else None)
+                A = ops.aggregate(spec, [x_dict[s] for s in src_types], self_t=x_dict[d])   # [n, (R+1)*H]
+                y = linear(A, cat[0], cat[1])
+                out[d] = y / len(ets) if self.aggr == "mean" else y
+                continue
+            W_l, b, W_r = sage_operands(*plist)                                          # [out, R*H], [out], [out, H]
+            if no_edges:
                 # No relation keeps an edge at this layer: every mean is zero, lin_l contributes its bias only.  This IS the
                 # last layer of the reference's default setup — num_layers convolutions over num_layers - 1 sampled hops
                 # (train/train_analysisgnn.py:154), trim_to_layer dropping hop 2's edges at layer 1 and hop 1's at layer 2
@@ -262,7 +279,7 @@ class _HybridMixin:
 
     # The sequence branch only needs the encoder INPUT, so it runs on a second HIP stream beside the
     # GNN stack (the persistent GRU kernels occupy 2*B of the 256 CUs and are latency bound); autograd
-    # replays the backward on the same streams.  Set to False to serialise (debugging / graph capture).
+    # replays the backward on the same streams.  Set to False to serialise (debugging).
     overlap_sequence_branch = True
 
     def _start_branch(self, x_in, batch_dict, batch_size):

@@ -55,18 +55,27 @@ class _GRULayer(torch.autograd.Function):
         # Everything that only feeds the optimizer leaves the recurrence chain (layer l-1's kernel waits for dx alone).
         # Forked AFTER dx is queued: the weight-gradient GEMMs then run beside the next layer's recurrence kernel
         # (64 of 256 CUs) instead of halving the speed of the dx GEMM the chain is waiting for.
-        with wgrad_stream(dev, dgi, dgh, y, x2, active=ctx.wg_async, kind="sequence"):
-            dw_ih, db_ih = weight_grad(dgi2, x2, True)
-            dw_ih, db_ih = dw_ih.view(2, 3 * Hh, I), db_ih.view(2, 3 * Hh)
-            hp = torch.zeros((B, T, 2, Hh), dtype=torch.float32, device=dev)             # h_{t-1} per direction
-            if T > 1:
-                hp[:, 1:, 0] = y[:, :-1, :Hh]
-                hp[:, :-1, 1] = y[:, 1:, Hh:]
+        dw_ih = torch.empty((6 * Hh, I), dtype=torch.float32, device=dev)
+        db_ih = torch.empty((6 * Hh,), dtype=torch.float32, device=dev)
+        dw_hh = torch.empty((2, 3 * Hh, Hh), dtype=torch.float32, device=dev)            # both directions land in the stacked
+        db_hh = torch.empty((2, 3 * Hh), dtype=torch.float32, device=dev)                # gradients directly (no torch.stack)
+        hp = torch.empty((B, T, 2, Hh), dtype=torch.float32, device=dev)                 # h_{t-1} per direction, one launch
+
+        def weight_grads():
+            if I % 2 == 0:
+                weight_grad(dgi2, x2, True, dw_out=dw_ih, db_out=db_ih)
+            else:                               # odd input width: the kernel pads a column, results are copied into place
+                dw, db = weight_grad(dgi2, x2, True)
+                dw_ih.copy_(dw)
+                db_ih.copy_(db)
+            _lib.check(lib.agnn_gru_hprev_f32(y.data_ptr(), B, T, Hh, hp.data_ptr(), _lib.stream_ptr(dev)), "agnn_gru_hprev_f32")
             dgh2, hp2 = dgh.view(B * T, 6 * Hh), hp.view(B * T, 2 * Hh)
-            parts = [weight_grad(dgh2[:, d * 3 * Hh:(d + 1) * 3 * Hh], hp2[:, d * Hh:(d + 1) * Hh], True) for d in range(2)]
-            dw_hh = torch.stack([p[0] for p in parts])
-            db_hh = torch.stack([p[1] for p in parts])
-        return dx, dw_ih, dw_hh, db_ih, db_hh
+            for d in range(2):
+                weight_grad(dgh2[:, d * 3 * Hh:(d + 1) * 3 * Hh], hp2[:, d * Hh:(d + 1) * Hh], True, dw_out=dw_hh[d], db_out=db_hh[d])
+
+        with wgrad_stream(dev, dgi, dgh, y, x2, hp, dw_ih, db_ih, dw_hh, db_hh, active=ctx.wg_async, kind="sequence"):
+            weight_grads()
+        return dx, dw_ih.view(2, 3 * Hh, I), dw_hh, db_ih.view(2, 3 * Hh), db_hh
 
 
 def kernel_applicable(rnn: nn.GRU) -> bool:

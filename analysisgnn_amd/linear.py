@@ -101,11 +101,13 @@ def _ok(t: torch.Tensor) -> bool:
             and t.shape[1] % 2 == 0 and t.data_ptr() % 8 == 0)
 
 
-def weight_grad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool):
+def weight_grad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool, dw_out: Optional[torch.Tensor] = None,
+                db_out: Optional[torch.Tensor] = None):
     """(dW [out, in], db [out] or None) for dy [N, out], x [N, in] on the HIP kernel; library GEMM when the
     shape / alignment does not fit the kernel.  An odd `in` is served when x has a spare (zero) column behind its last
     one — rows padded to an even stride, as models.encode lays out the 153-wide note input: the kernel then runs on
-    in + 1 columns and the extra gradient column is dropped."""
+    in + 1 columns and the extra gradient column is dropped.  `dw_out` [out, in] / `db_out` [out] (contiguous, even `in`):
+    write the results there (a slot of a stacked gradient) instead of into fresh tensors."""
     n, out_f = dy.shape
     in_f = x.shape[1]
     in_k = in_f
@@ -115,11 +117,21 @@ def weight_grad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool):
     if not (ENABLED and dy.is_cuda and n >= MIN_ROWS and out_f * in_k <= MAX_OUT_IN and _ok(dy) and _ok(x)):
         if in_k != in_f:
             x = x[:, :in_f]
+        if dw_out is not None:
+            torch.mm(dy.t(), x, out=dw_out)
+            if want_bias:
+                torch.sum(dy, dim=0, out=db_out)
+            return dw_out, (db_out if want_bias else None)
         return dy.t() @ x, (dy.sum(dim=0) if want_bias else None)
     lib = _lib.load()
     dev = dy.device
-    dw = torch.empty((out_f, in_k), dtype=torch.float32, device=dev)
-    db = torch.empty((out_f,), dtype=torch.float32, device=dev) if want_bias else None
+    if dw_out is not None:
+        if in_k != in_f or tuple(dw_out.shape) != (out_f, in_f) or not dw_out.is_contiguous() or (want_bias and (db_out is None or not db_out.is_contiguous())):
+            raise _lib.AgnnError("weight_grad: dw_out / db_out must be contiguous [out, in] / [out] with an even `in`")
+        dw, db = dw_out, (db_out if want_bias else None)
+    else:
+        dw = torch.empty((out_f, in_k), dtype=torch.float32, device=dev)
+        db = torch.empty((out_f,), dtype=torch.float32, device=dev) if want_bias else None
     nws = int(lib.agnn_wgrad_workspace_bytes(n, out_f, in_k))
     ws = torch.empty(nws, dtype=torch.uint8, device=dev)
     _lib.check(lib.agnn_wgrad_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), n, out_f, in_k, dw.data_ptr(),

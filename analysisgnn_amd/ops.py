@@ -30,6 +30,7 @@ class AggSpec:
     skip_self: bool = False
     col_limit: int = _lib.INT32_MAX
     edge_weight: Optional[List[Optional[torch.Tensor]]] = None   # per relation, COO order, no grad
+    root: bool = False                   # `self` is a SAGE layer's root operand: output [n_rows, (R+1)*H], last slot = self[:n_rows]
 
     def limit(self, r: int) -> Optional[int]:
         return None if self.e_limit is None else self.e_limit[r]
@@ -43,12 +44,13 @@ def _view_ok(t: torch.Tensor) -> bool:
 # When set to a list, every SpMM launch is bracketed by HIP events on the launch stream and
 # (tag, start_event, end_event, n_rel, n_rows, H, rel_stride) is appended — bench.py's live kernel timing.
 SPMM_TRACE: Optional[list] = None
+ROOT_WIDTHS = (256, 512)   # agnn_spmm_root_f32 exists for the widths of the specialised kernel
 SPMM_VARIANT = 0           # tests / A-B timing: 1024 = AGNN_SPMM_GENERIC (never take the fast path)
 
 
 def _launch(rels: Sequence[dict], n_rows: int, H: int, out: torch.Tensor, rel_stride: int,
             self_t: Optional[torch.Tensor], inv_cnt: Optional[torch.Tensor], col_limit: int, flags: int,
-            tag: str = "spmm"):
+            tag: str = "spmm", root_rows: Optional[int] = None):
     lib = _lib.load()
     dev = out.device
     arr = _lib.make_rels(rels)
@@ -57,14 +59,19 @@ def _launch(rels: Sequence[dict], n_rows: int, H: int, out: torch.Tensor, rel_st
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(dev))
-    rc = lib.agnn_spmm_f32(len(rels), arr, n_rows, H, out.data_ptr(), out.stride(0), rel_stride,
-                           _lib.ptr(self_t), self_t.stride(0) if self_t is not None else 0,
-                           _lib.ptr(inv_cnt), min(int(col_limit), _lib.INT32_MAX), flags | SPMM_VARIANT,
-                           _lib.stream_ptr(dev))
+    if root_rows is not None:
+        rc = lib.agnn_spmm_root_f32(len(rels), arr, n_rows, H, out.data_ptr(), out.stride(0), rel_stride, self_t.data_ptr(),
+                                    self_t.stride(0), root_rows, _lib.ptr(inv_cnt), min(int(col_limit), _lib.INT32_MAX), flags,
+                                    _lib.stream_ptr(dev))
+    else:
+        rc = lib.agnn_spmm_f32(len(rels), arr, n_rows, H, out.data_ptr(), out.stride(0), rel_stride,
+                               _lib.ptr(self_t), self_t.stride(0) if self_t is not None else 0,
+                               _lib.ptr(inv_cnt), min(int(col_limit), _lib.INT32_MAX), flags | SPMM_VARIANT,
+                               _lib.stream_ptr(dev))
     if trace is not None:
         e1.record(torch.cuda.current_stream(dev))
         trace.append((tag, e0, e1, len(rels), n_rows, H, rel_stride))
-    _lib.check(rc, "agnn_spmm_f32")
+    _lib.check(rc, "agnn_spmm_root_f32" if root_rows is not None else "agnn_spmm_f32")
 
 
 def _perm_weights(csr: Csr, w: torch.Tensor) -> torch.Tensor:
@@ -94,7 +101,12 @@ class _Aggregate(torch.autograd.Function):
             self_c = self_t if _view_ok(self_t) else _lib.f32c(self_t)
             if self_c.shape[0] < n or self_c.shape[1] != H:
                 raise _lib.AgnnError("`self` must have at least n_rows rows and width H")
-        width = H if spec.shared_slot else R * H
+        if spec.root:
+            if spec.shared_slot or self_c is None or spec.edge_weight is not None or H not in ROOT_WIDTHS:
+                raise _lib.AgnnError("root aggregation: per-relation slots, a root operand, no edge weights, H in (256, 512)")
+            width = (R + 1) * H
+        else:
+            width = H if spec.shared_slot else R * H
         out = torch.empty((n, width), dtype=torch.float32, device=dev)
         inv_cnt = torch.empty((R, max(n, 1)), dtype=torch.float32, device=dev) if spec.mean else None
         rels = []
@@ -113,7 +125,8 @@ class _Aggregate(torch.autograd.Function):
                              col=csr.col.data_ptr(), ew=_lib.ptr(ew), ld_src=src.stride(0)))
         flags = (_lib.SPMM_MEAN if spec.mean else 0) | (_lib.SPMM_SKIP_SELF if spec.skip_self else 0)
         if n > 0:
-            _launch(rels, n, H, out, 0 if spec.shared_slot else H, self_c, inv_cnt, spec.col_limit, flags, tag="fwd")
+            _launch(rels, n, H, out, 0 if spec.shared_slot else H, self_c, inv_cnt, spec.col_limit, flags, tag="fwd",
+                    root_rows=n if spec.root else None)
         ctx.spec = spec
         ctx.H = H
         ctx.src_rows = [s.shape[0] for s in srcs]
@@ -139,6 +152,7 @@ class _Aggregate(torch.autograd.Function):
         dout = dout if _view_ok(dout) else _lib.f32c(dout)
         dev = dout.device
         grads: List[Optional[torch.Tensor]] = []
+        root_folded = False
         n_srcs = len(ctx.src_rows)
         for k in range(n_srcs):
             if not ctx.needs_input_grad[2 + k]:
@@ -165,16 +179,27 @@ class _Aggregate(torch.autograd.Function):
                                  col=csr.col.data_ptr(), ew=_lib.ptr(ew),
                                  colscale=(inv_cnt[r].data_ptr() if inv_cnt is not None else None),
                                  ld_src=dout.stride(0)))
+            # root aggregation: the root slot's gradient is one more addend of this launch when the root operand IS this
+            # source (x_dst of a note -> note relation), so neither a padded copy nor a gradient add is ever issued
+            fold_root = spec.root and k == ctx.self_src and ctx.needs_input_grad[1] and rels and rows_t >= n > 0
             if not rels or rows_t == 0 or n == 0:
                 g.zero_()
             else:
                 flags = _lib.SPMM_SKIP_SELF if spec.skip_self else 0
                 # only a trimmed forward (fewer output rows than the CSR has) needs the column filter
                 lim = n if any(c.n_rows > n for c in spec.fwd) else _lib.INT32_MAX
-                _launch(rels, rows_t, H, g, 0, None, None, lim, flags, tag="bwd")
+                if fold_root:
+                    _launch(rels, rows_t, H, g, 0, dout[:, R * H:], None, lim, flags, tag="bwd", root_rows=n)
+                    root_folded = True
+                else:
+                    _launch(rels, rows_t, H, g, 0, None, None, lim, flags, tag="bwd")
             grads.append(g)
         gself = None
-        if ctx.has_self and ctx.needs_input_grad[1] and n > 0:
+        if spec.root:
+            if ctx.needs_input_grad[1] and not root_folded:
+                gself = torch.zeros((ctx.self_rows, H), dtype=torch.float32, device=dev)
+                gself[:n] = dout[:, R * H:]
+        elif ctx.has_self and ctx.needs_input_grad[1] and n > 0:
             # d/d self = sum_r dout_r * (1/cnt_r | 1): one launch (agnn_spmm_self_grad_f32), added straight onto the source's
             # gradient when self and that source are one matrix (autograd would otherwise add the two with another launch)
             lib = _lib.load()

@@ -79,6 +79,65 @@ class _SageOperands(torch.autograd.Function):
         return (None, *G_l.unbind(0), *G_b.unbind(0), *G_r.unbind(0))
 
 
+class _SageOperandsCat(torch.autograd.Function):
+    """(W [out, (R+1)*in] = [W_l_1 .. W_l_R | sum_r W_r_r], b [out]): the operand of the ONE GEMM of a SAGE layer whose root
+    operand rides along with the aggregation (ops.AggSpec.root).  `with_l=False`: only (sum_r W_r_r, b) — the layer that
+    keeps no edge uses nothing else (lin_l.weight then gets a zero gradient from one fill)."""
+
+    @staticmethod
+    def forward(ctx, R: int, with_l: bool, *params):
+        w_l, b_l, w_r = params[:R], params[R:2 * R], params[2 * R:]
+        dev = _lib.require_gpu(*params)
+        out_f, in_f = w_r[0].shape
+        nl = R if with_l else 0
+        W = torch.empty((out_f, (nl + 1) * in_f), dtype=torch.float32, device=dev)
+        b = torch.empty((out_f,), dtype=torch.float32, device=dev)
+        items = [(W[:, r * in_f:(r + 1) * in_f], [w_l[r].detach()]) for r in range(nl)]
+        items.append((b.view(1, -1), [t.detach().view(1, -1) for t in b_l]))
+        items.append((W[:, nl * in_f:], [t.detach() for t in w_r]))
+        pack(items, dev)
+        ctx.R, ctx.nl = R, nl
+        ctx.shape = (out_f, in_f)
+        ctx.leaves = all(t.is_leaf for t in params)
+        return W, b
+
+    @staticmethod
+    def backward(ctx, dW, db):
+        R, nl = ctx.R, ctx.nl
+        out_f, in_f = ctx.shape
+        dev = dW.device
+        G_l = torch.empty((nl, out_f, in_f), dtype=torch.float32, device=dev)
+        G_b = torch.empty((R, out_f), dtype=torch.float32, device=dev)
+        G_r = torch.empty((R, out_f, in_f), dtype=torch.float32, device=dev)
+        with wgrad_stream(dev, dW, db, active=ctx.leaves):
+            dW, db = _lib.f32c(dW), db.contiguous()
+            items = []
+            for r in range(R):
+                if r < nl:
+                    items.append((G_l[r], [dW[:, r * in_f:(r + 1) * in_f]]))
+                items.append((G_b[r].view(1, -1), [db.view(1, -1)]))
+                items.append((G_r[r], [dW[:, nl * in_f:]]))
+            pack(items, dev)
+        if not nl:    # unused this step, yet still a parameter of the step: a zero gradient (as the reference's zeros @ W gives), not None
+            G_l = torch.zeros((R, out_f, in_f), dtype=torch.float32, device=dev)
+        return (None, None, *G_l.unbind(0), *G_b.unbind(0), *G_r.unbind(0))
+
+
+def sage_operands_cat(w_l: List[torch.Tensor], b_l: List[torch.Tensor], w_r: List[torch.Tensor], with_l: bool = True):
+    """([W_l_1 .. W_l_R | sum W_r], sum b) — or (sum W_r, sum b) with `with_l=False` — in one launch; None when the
+    parameters do not fit the pack kernel (the caller then takes `sage_operands`)."""
+    R = len(w_l)
+    ok = (w_l[0].is_cuda and R <= _lib.PACK_MAX_SRC and all(t is not None for t in b_l)
+          and all(t.shape == w_l[0].shape and t.is_contiguous() for t in (*w_l, *w_r)))
+    if not ok:
+        return None
+    ops_ = _SageOperandsCat.apply(R, with_l, *w_l, *b_l, *w_r)
+    if all(t.is_leaf for t in (*w_l, *b_l, *w_r)):
+        for t in ops_:
+            mark_wgrad_async(t)
+    return ops_
+
+
 def sage_operands(w_l: List[torch.Tensor], b_l: List[torch.Tensor], w_r: List[torch.Tensor]):
     R = len(w_l)
     ok = (w_l[0].is_cuda and R <= _lib.PACK_MAX_SRC and all(t is not None for t in b_l)

@@ -106,6 +106,18 @@ def make_labels(n, device, seed, tasks):
     return {t: torch.randint(0, c, (n,), generator=g).to(device) for t, c in tasks.items()}
 
 
+def _dump_capture_dot(path: str, dev) -> None:
+    """Inside a stream capture: write the graph captured so far as DOT (hipStreamGetCaptureInfo_v2 + hipGraphDebugDotPrint)."""
+    import ctypes as C
+    import torch
+    hip = C.CDLL("libamdhip64.so")
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    status, cid, graph, deps, ndeps = C.c_int(0), C.c_ulonglong(0), C.c_void_p(0), C.c_void_p(0), C.c_size_t(0)
+    rc = hip.hipStreamGetCaptureInfo_v2(stream, C.byref(status), C.byref(cid), C.byref(graph), C.byref(deps), C.byref(ndeps))
+    rc2 = hip.hipGraphDebugDotPrint(graph, path.encode(), C.c_uint(0)) if rc == 0 and graph.value else -1
+    print(f"[bench] capture graph -> {path}: hipStreamGetCaptureInfo_v2 rc={rc} status={status.value}, hipGraphDebugDotPrint rc={rc2}", file=sys.stderr)
+
+
 def build_workload(name: str, rank: int, world: int, n_sub: int = N_SUB):
     """(graph, encoder_type, hidden, layers, tasks).  Rank r of G takes subgraphs {i : i mod G = r} of the global batch of
     32 * G (dp.shard_units; DistributedSampler semantics): independent units, no data-path collective."""
@@ -286,8 +298,11 @@ def main():
             torch.cuda.current_stream(dev).wait_stream(side)
             dp.barrier_and_sync()                               # no collective in flight on any rank while capturing
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            dot = os.environ.get("AGNN_GRAPH_DOT")               # the captured step's dependency graph as DOT (debugging)
             with torch.cuda.graph(g1):
                 loss_ref[0] = fwd_bwd()
+                if dot:
+                    _dump_capture_dot(dot, dev)
             with torch.cuda.graph(g2):
                 update()
             graphs = (g1, g2)

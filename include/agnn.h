@@ -147,6 +147,7 @@ typedef struct {
 #define AGNN_SPMM_MEAN      1u
 #define AGNN_SPMM_SKIP_SELF 2u
 #define AGNN_SPMM_ACCUM     4u
+#define AGNN_SPMM_ROOT      8u  /* set by agnn_spmm_root_f32 (internal) */
 #define AGNN_SPMM_GENERIC 1024u /* never take the specialised fast path (tests / A/B timing) */
 #define AGNN_SPMM_FAST_V4 2048u /* fast path: the older one-relation-at-a-time kernel (A/B timing) */
 
@@ -154,6 +155,18 @@ int agnn_spmm_f32(int n_rel, const agnn_rel_t* rels /* (host) */, int64_t n_rows
                   float* out, int64_t ld_out, int64_t rel_stride,
                   const float* self, int64_t ld_self,
                   float* inv_cnt, int32_t col_limit, uint32_t flags, agnn_stream_t stream);
+
+/* The same aggregation with the ROOT operand of a SAGE layer riding along, so that PyG `SAGEConv`'s
+ * `lin_l(mean_j x_j) + lin_r(x_i)` summed over the relations of a destination type (ref: models/cadence.py:147-159,174) is ONE
+ * GEMM over [A_1 .. A_R | x_dst] and its backward ONE transposed launch (no slice gradient, no gradient add):
+ *   rel_stride != 0 (forward):  out[i, r*rel_stride + 0:H] as agnn_spmm_f32, and out[i, n_rel*rel_stride + 0:H] = root[i]
+ *                               (root_rows >= n_rows, ld_out >= n_rel*rel_stride + H);
+ *   rel_stride == 0 (backward): out[i] = sum_r (...)  +  (i < root_rows ? root[i] : 0).
+ * H must be 256 or 512, no per-edge weights; flags: AGNN_SPMM_MEAN, AGNN_SPMM_SKIP_SELF. */
+int agnn_spmm_root_f32(int n_rel, const agnn_rel_t* rels /* (host) */, int64_t n_rows, int32_t H,
+                       float* out, int64_t ld_out, int64_t rel_stride,
+                       const float* root, int64_t ld_root, int64_t root_rows,
+                       float* inv_cnt, int32_t col_limit, uint32_t flags, agnn_stream_t stream);
 
 /* Gradient of agnn_spmm_f32 w.r.t. its `self` operand, optionally added onto an existing gradient:
  *     out[i, 0:H] (=|+=) sum_{r < n_rel} dout[i*ld_dout + r*rel_stride + 0:H] * (inv_cnt ? inv_cnt[r*ld_inv + i] : 1)
@@ -182,6 +195,9 @@ int agnn_gru_fwd_f32(const float* gi, const float* w_hh, const float* b_hh, int6
 int agnn_gru_bwd_f32(const float* dy, const float* y, const float* saved, const float* w_hh,
                      int64_t B, int64_t T, int32_t hidden, float* dgi, float* dgh,
                      agnn_stream_t stream);
+/* hp [B, T, 2, hidden]: the previous hidden state of each direction (forward: y[b, t-1, :hidden], reverse:
+ * y[b, t+1, hidden:], zero at the sequence ends) — the operand of the W_hh weight-gradient GEMMs, in one launch. */
+int agnn_gru_hprev_f32(const float* y, int64_t B, int64_t T, int32_t hidden, float* hp, agnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * HGT edge-softmax attention = message / softmax / aggregate of PyG `HGTConv`, reached through

@@ -1,40 +1,63 @@
 #!/usr/bin/env python3
-"""Does a forked branch start when its dependency completes if the main chain keeps the GPU full?  Main chain: 24 big
-GEMMs ([16000,1024]x[1024,256], ~75 us, every CU busy); after GEMM #3 a side stream is forked and runs 12 kernels of
-kind argv[2] (sin: element-wise, gemm: [16000,256]x[256,256]).  argv[1] = graph | eager.  Run under rocprofv3
---kernel-trace; scripts/fork_probe_report.py prints when the side branch actually started."""
-import sys, torch
-dev = "cuda:0"
-mode = sys.argv[1] if len(sys.argv) > 1 else "graph"
-kind = sys.argv[2] if len(sys.argv) > 2 else "sin"
-a = torch.randn(16000, 1024, device=dev); w = torch.randn(1024, 1024, device=dev) * 0.03
-b = torch.randn(16000, 256, device=dev); v = torch.randn(256, 256, device=dev) * 0.06
-big = torch.randn(16 * 1024 * 1024 // 4, device=dev)
-side = torch.cuda.Stream()
-def work():
-    x = a
-    for i in range(24):
-        x = x @ w
-        if i == 3:
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                y = big if kind == "sin" else b
-                for _ in range(12):
-                    y = torch.sin(y) if kind == "sin" else torch.tanh(y @ v)
-    torch.cuda.current_stream().wait_stream(side)
-    return x, y
-s = torch.cuda.Stream()
-s.wait_stream(torch.cuda.current_stream())
-with torch.cuda.stream(s):
-    for _ in range(3): work()
-torch.cuda.current_stream().wait_stream(s)
+"""How does a replayed hipGraph schedule two independent chains that fork from one node?  Stream M: A (long), m1..mK (short);
+stream S forks after A: s1..sJ.  Captured M-chain-first or S-chain-first; the replay's kernel trace (rocprofv3) shows when
+s1 and m1 start relative to the end of A.  Kernels are told apart by their element counts (grid sizes) in the trace.
+usage: graph_fork_probe.py <order: m_first|s_first> [K] [J] [SZ]"""
+import sys
+
+import torch
+
+order = sys.argv[1]
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+J = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+dev = torch.device("cuda:0")
+SZ = int(sys.argv[4]) if len(sys.argv) > 4 else 8192      # A = SZ^3 matmul: 8192 -> ~7 ms, 2048 -> ~0.15 ms
+a = torch.randn(SZ, SZ, device=dev)
+b = torch.randn(SZ, SZ, device=dev)
+c = torch.empty(SZ, SZ, device=dev)
+xm = torch.randn(3_000_000, device=dev)      # "m" kernels: sin_ on 3.0 M elements
+xs = torch.randn(5_000_000, device=dev)      # "s" kernels: cos_ on 5.0 M elements
+side = torch.cuda.Stream(device=dev)
+
+
+def m_chain():
+    for _ in range(K):
+        xm.sin_()
+
+
+def s_chain(main):
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        for _ in range(J):
+            xs.cos_()
+
+
+def body():
+    main = torch.cuda.current_stream(dev)
+    torch.mm(a, b, out=c)                     # A
+    if order == "m_first":
+        ev = torch.cuda.Event()
+        ev.record(main)                       # the fork point is the end of A in both orders
+        m_chain()
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            for _ in range(J):
+                xs.cos_()
+    else:
+        s_chain(main)
+        m_chain()
+    main.wait_stream(side)
+    xm.add_(1.0)                              # join
+
+
+warm = torch.cuda.Stream(device=dev)
+with torch.cuda.stream(warm):
+    body()
 torch.cuda.synchronize()
-if mode == "graph":
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        out = work()
-    torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    body()
+for _ in range(12):
     g.replay()
-else:
-    work()
 torch.cuda.synchronize()
+print("done", order, K, J)

@@ -20,6 +20,8 @@ from analysisgnn_amd.models import onset_pool  # noqa: E402
 from analysisgnn_amd.synth import make_sampled_batch, torch_inputs  # noqa: E402
 
 REP = int(os.environ.get("REP", "40"))
+WITH_ROOT = os.environ.get("ROOT", "0") == "1"      # the SAGE layer's root operand rides along (agnn_spmm_root_f32)
+TIMES = os.environ.get("TIMES", "0") == "1"         # HIP events around every launch: average microseconds per layer and direction
 H = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 dev = torch.device("cuda:0")
 g = make_sampled_batch(32, 500, (5, 5))
@@ -35,13 +37,21 @@ for layer in range(3):
     n_src = plan.n_keep[layer - 1]["note"] if layer else n_nodes["note"]
     e_keep = [plan.e_keep[layer][et] for et in ets]
     spec = ops.AggSpec(fwd=[hix.fwd[e] for e in ets], bwd=[hix.bwd[e] for e in ets], src_id=[0] * len(ets), n_rows=n_dst, mean=True,
-                       shared_slot=False, e_limit=e_keep if any(k is not None for k in e_keep) else None)
+                       shared_slot=False, e_limit=e_keep if any(k is not None for k in e_keep) else None, root=WITH_ROOT)
     x = torch.randn(n_src, H, device=dev, requires_grad=True)
-    gout = torch.randn(n_dst, len(ets) * H, device=dev)
+    gout = torch.randn(n_dst, (len(ets) + WITH_ROOT) * H, device=dev)
+    if TIMES:
+        ops.SPMM_TRACE = []
     for _ in range(REP):
-        out = ops.aggregate(spec, [x])
+        out = ops.aggregate(spec, [x], self_t=x if WITH_ROOT else None)
         out.backward(gout)
         x.grad = None
+    if TIMES:
+        torch.cuda.synchronize()
+        tr, ops.SPMM_TRACE = ops.SPMM_TRACE, None
+        for tag in ("fwd", "bwd"):
+            us = sorted(e0.elapsed_time(e1) * 1e3 for t, e0, e1, *_ in tr if t == tag)
+            print(f"layer {layer} {tag} root={int(WITH_ROOT)}: median {us[len(us) // 2]:.1f} us  p10 {us[len(us) // 10]:.1f}", file=sys.stderr)
     idx, e_kept, srcs = 0, 0, []
     for et, k in zip(ets, e_keep):
         ei = g.edge_index[et][:, :k] if k is not None else g.edge_index[et]

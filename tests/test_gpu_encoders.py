@@ -73,6 +73,47 @@ def test_hybrid_gnn(kind, aggr):
     _cmp_grads(m, P)
 
 
+@pytest.mark.parametrize("kind", ["metrical", "sampled"])
+@pytest.mark.parametrize("aggr", ["sum", "mean"])
+def test_hybrid_gnn_width_256_one_gemm_layers(kind, aggr):
+    """H = 256 is where a SAGE layer runs as ONE GEMM over [mean_1 .. mean_R | x_dst] (agnn_spmm_root_f32, encoders.HeteroConv):
+    outputs, input gradients and every parameter gradient against the CPU restatement, on a trimmed sampled batch (the
+    root's gradient folds into the transposed launch) and on a heterogeneous batch (destination types whose root operand
+    is not among the sources)."""
+    from analysisgnn_amd import ops
+    from analysisgnn_amd.encoders import HybridGNN
+    from analysisgnn_amd.synth import torch_inputs
+    from oracle import encoders_ref as E
+    g = _graph(kind)
+    H, L = 256, 3
+    torch.manual_seed(1)
+    m = HybridGNN(metadata=g.metadata(), input_channels=H, hidden_channels=H, num_layers=L, dropout=0.0, use_jk=False, aggr=aggr).train()
+    P = _cpu_params(m)
+    m = m.to(DEV)
+    I = torch_inputs(g, in_channels=H, seed=2)
+    xc = {k: v.clone().requires_grad_(True) for k, v in I["x_dict"].items()}
+    ref = E.hybrid_gnn(P, "", g.metadata(), L, xc, I["edge_index_dict"], I["batch_dict"], I["batch_size"],
+                       I["neighbor_mask_node"], I["neighbor_mask_edge"], use_jk=False, aggr=aggr)
+    xg = {k: v.to(DEV).requires_grad_(True) for k, v in I["x_dict"].items()}
+    ops.SPMM_TRACE = []
+    try:
+        out = m(x_dict=xg, edge_index_dict={k: v.to(DEV) for k, v in I["edge_index_dict"].items()},
+                batch_dict={k: v.to(DEV) for k, v in I["batch_dict"].items()}, batch_size=I["batch_size"],
+                neighbor_mask_node=I["neighbor_mask_node"], neighbor_mask_edge=I["neighbor_mask_edge"])
+        gout = torch.randn(ref.shape, generator=torch.Generator().manual_seed(9))
+        (out * gout.to(DEV)).sum().backward()
+        launches = [t[0] for t in ops.SPMM_TRACE]
+    finally:
+        ops.SPMM_TRACE = None
+    assert "fwd" in launches and "bwd" in launches
+    assert_close(out, ref, TOL, "out")
+    (ref * gout).sum().backward()
+    for k in xc:
+        if xc[k].grad is not None:
+            assert_close(xg[k].grad, xc[k].grad, TOL, f"grad x[{k}]")
+    _cmp_grads(m, P)
+
+
 def test_hop_index_tensor_masks_equal_count_lists():
     """graphmuse-style per-element hop-index tensors (pitch_spelling.py:388-391) give the same result as
     PyG per-hop count lists (datamodules/analysis.py:277)."""

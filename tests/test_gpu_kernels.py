@@ -82,7 +82,7 @@ def test_rowend_matches_oracle():
 
 
 def _spmm_case(n_dst, n_src, es, H, mean, shared, with_self, skip_self=False, col_limit=None, trim=None, seed=0,
-               colscale=False):
+               colscale=False, root_rows=None):
     from analysisgnn_amd import _lib, ops
     dev = _dev()
     rng = np.random.default_rng(seed)
@@ -109,13 +109,22 @@ def _spmm_case(n_dst, n_src, es, H, mean, shared, with_self, skip_self=False, co
         grels.append(dict(src=st.data_ptr(), rowptr=csrs[r].rowptr.data_ptr(), rowend=_lib.ptr(re_g),
                           col=csrs[r].col.data_ptr(), colscale=_lib.ptr(cst), ld_src=st.stride(0)))
     lim = col_limit if col_limit is not None else 2 ** 31 - 1
-    exp, inv_o = c_oracle.spmm(orels, n_rows, H, 0 if shared else H, self_=x, mean=mean, skip_self=skip_self,
-                               col_limit=lim, want_inv_cnt=True)
-    out = torch.full((n_rows, H if shared else R * H), float("nan"), device=dev)
+    exp, inv_o = c_oracle.spmm(orels, n_rows, H, 0 if shared else H, self_=None if root_rows is not None else x, mean=mean,
+                               skip_self=skip_self, col_limit=lim, want_inv_cnt=True)
+    if root_rows is not None:
+        # agnn_spmm_root_f32: the root operand is an extra slot (forward) / one more addend for the rows it has (backward)
+        if shared:
+            exp = exp.copy()
+            exp[:root_rows] += x[:root_rows]
+        else:
+            exp = np.concatenate([exp, x[:n_rows]], axis=1)
+    out = torch.full((n_rows, H if shared else (R + (root_rows is not None)) * H), float("nan"), device=dev)
     inv = torch.empty((R, n_rows), device=dev)
     xt = torch.from_numpy(x).to(dev) if with_self else None
+    if root_rows is not None and shared:
+        xt = xt[:root_rows].contiguous()         # the slot really is shorter than the output
     flags = (_lib.SPMM_MEAN if mean else 0) | (_lib.SPMM_SKIP_SELF if skip_self else 0)
-    ops._launch(grels, n_rows, H, out, 0 if shared else H, xt, inv, lim, flags)
+    ops._launch(grels, n_rows, H, out, 0 if shared else H, xt, inv, lim, flags, root_rows=root_rows)
     torch.cuda.synchronize()
     got = out.cpu().numpy()
     assert not np.isnan(got).any()
@@ -192,6 +201,24 @@ def test_fast_path_trimmed_and_filtered(H, variant):
         _spmm_case(40, 500, [3000], H, mean=True, shared=False, with_self=False, trim=[2999], seed=H + 6)
     finally:
         ops.SPMM_VARIANT = 0
+
+
+@pytest.mark.parametrize("H", [256, 512])
+def test_root_operand_rides_along(H):
+    """agnn_spmm_root_f32: forward = the relations' slots plus the root rows as one more slot; backward = the transposed
+    aggregation plus the root slot's gradient for the first root_rows rows (trimmed, column-limited, 1/deg scales)."""
+    _spmm_case(300, 300, [1500, 40, 700, 0, 90], H, mean=True, shared=False, with_self=True, trim=[900, 40, 1, 0, 0],
+               seed=H + 11, root_rows=300)
+    _spmm_case(300, 300, [1500, 40, 700, 0, 90], H, mean=False, shared=True, with_self=True, colscale=True,
+               trim=[900, 40, 1, 0, 0], col_limit=211, seed=H + 12, root_rows=211)
+    _spmm_case(64, 64, [200], H, mean=False, shared=True, with_self=True, colscale=True, seed=H + 13, root_rows=64)
+    _spmm_case(40, 500, [3000], H, mean=True, shared=False, with_self=True, seed=H + 14, root_rows=40)
+
+
+def test_root_operand_rejects_what_the_kernel_does_not_cover():
+    from analysisgnn_amd import _lib
+    with pytest.raises(_lib.AgnnError):
+        _spmm_case(30, 30, [100], 64, mean=True, shared=False, with_self=True, root_rows=30)
 
 
 def test_spmm_c2_shape_against_oracle():

@@ -12,10 +12,10 @@ DEV = "cuda:0"
 
 @pytest.mark.parametrize("n,out_f,in_f", [(2048, 2, 2), (4097, 64, 128), (16000, 256, 256), (16000, 256, 1024),
                                           (16000, 1344, 128), (5000, 130, 66), (16000, 690, 1344), (16001, 768, 256)])
-def test_wgrad_matches_reference(n, out_f, in_f):
+def test_wgrad_matches_reference(n, out_f, in_f, monkeypatch):
     from analysisgnn_amd import linear
     from analysisgnn_amd.linear import weight_grad
-    linear.MAX_OUT_IN = 1 << 40                      # exercise the kernel on every shape, not only the dispatched ones
+    monkeypatch.setattr(linear, "MAX_OUT_IN", 1 << 40)   # exercise the kernel on every shape, not only the dispatched ones
     g = torch.Generator().manual_seed(n + out_f)
     dy = torch.randn(n, out_f, generator=g)
     x = torch.randn(n, in_f, generator=g)
@@ -26,6 +26,24 @@ def test_wgrad_matches_reference(n, out_f, in_f):
     assert_close(db, ref_b, 1e-4, "db")
     dw2, none = weight_grad(dy.to(DEV), x.to(DEV), False)
     assert none is None and torch.equal(dw2, dw)                    # deterministic, bias optional
+
+
+def test_results_land_in_given_slots():
+    """dw_out / db_out: the two directions of a GRU layer write straight into the stacked [2, 3H, H] / [2, 3H] gradients."""
+    from analysisgnn_amd.linear import weight_grad
+    g = torch.Generator().manual_seed(3)
+    dy = torch.randn(4096, 2 * 384, generator=g).to(DEV)
+    x = torch.randn(4096, 2 * 128, generator=g).to(DEV)
+    dw = torch.full((2, 384, 128), float("nan"), device=DEV)
+    db = torch.full((2, 384), float("nan"), device=DEV)
+    for d in range(2):
+        r = weight_grad(dy[:, d * 384:(d + 1) * 384], x[:, d * 128:(d + 1) * 128], True, dw_out=dw[d], db_out=db[d])
+        assert r[0].data_ptr() == dw[d].data_ptr() and r[1].data_ptr() == db[d].data_ptr()
+        assert_close(dw[d], (dy[:, d * 384:(d + 1) * 384].double().t() @ x[:, d * 128:(d + 1) * 128].double()).float(), 1e-4)
+        assert_close(db[d], dy[:, d * 384:(d + 1) * 384].double().sum(0).float(), 1e-4)
+    small = weight_grad(dy[:100, :384], x[:100, :128], True, dw_out=dw[0], db_out=db[0])      # below MIN_ROWS: library, same slots
+    assert small[0].data_ptr() == dw[0].data_ptr()
+    assert_close(dw[0], (dy[:100, :384].double().t() @ x[:100, :128].double()).float(), 1e-4)
 
 
 def test_strided_views_and_fallback():
