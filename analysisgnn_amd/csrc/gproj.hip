@@ -13,6 +13,8 @@
 //   k_gproj_dw   dw[off_g + c, k] = sum_n dout[n, off_g + c] a[n, g*K + k] and db: both operands "n-major", row pairs
 //                per MFMA step, N cut into S slices -> slabs -> agnn::launch_slab_reduce (fixed order, no atomics).
 // Lanes past a group's class count read the group's last class (valid memory) and their results are never stored.
+#include <cstdlib>
+
 #include "agnn_common.h"
 
 namespace {
@@ -104,6 +106,207 @@ __global__ __launch_bounds__(256) void k_gproj_fwd(GpArgs p) {
     }
     __syncthreads();                                   // buffer `buf` free for tile ct + 2, tile ct + 1 visible
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Whole-row forward (K = 64): one workgroup (8 waves) = 64 rows x ALL groups, so a logits row leaves one CU.
+// profiles/r01_gproj_pmc.md: in the kernel above a row is written by 21 workgroups on different XCDs (one per group) in
+// 8 ... 740-byte strips, ~20 of its 60 us go to those stores, and its phases (stage `a`, stage a weight tile, 32 dependent
+// MFMAs, store) are serial with ~3 workgroups per CU.  Here:
+//   * `a` streams through LDS in chunks of 256 columns (four groups): one wave instruction reads 1 KB of ONE row (the access
+//     shape the norm kernels reach 5 TB/s with), 8 rows per wave and chunk, into a 64 x 260-float image (row stride 65 x 16
+//     bytes: the 16-byte fragment reads of 16 rows hit 16 different bank groups); chunk c + 1 is in registers while chunk c
+//     is computed; the chunk's logits are assembled in a 64 x 308-float image and leave as whole row pieces (256
+//     contiguous bytes per store instruction instead of four 64-byte pieces); two barriers per chunk.
+//     (Fragments read straight from global memory — 64-byte pieces of 16 rows per
+//     instruction — cost 31 of 55 us: profiles/r02_gproj.md.)
+//   * v_mfma_f32_16x16x4_f32 tiles, 16 rows x 16 classes: classes are padded to 16 instead of 32 (848 instead of 1088
+//     padded classes for the 21 heads).  Lane (i = lane & 15, q = lane >> 4) owns k = 16u + 4q + e (u, e < 4) of BOTH
+//     operands — any k order serves as long as A and B agree — so the four float4 of a lane ARE its 16 operand registers;
+//   * the 16-class tiles of a chunk's groups go round-robin to the 8 waves; a weight tile (16 classes x 64 = 4 KB, L2) is
+//     fetched once per 64 rows — while the wave's previous tile is computed — and used by four row tiles (64 MFMAs);
+//   * two accumulators per row tile (even / odd k-steps): the 16-step chain is issue-bound (32 cycles), not latency-bound (40).
+// D layout of the 16x16 tile: column = lane & 15 (class), rows 4q + r in register r.
+// ------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kGpMaxTiles16 = 128;      // capacity of the flat tile list (host: n_tiles32 <= 64, a 32-class tile is at most two)
+constexpr int kGpLdA = 260;             // floats per LDS row of a chunk of `a` (256 + 4)
+constexpr int kGpLdO = 308;             // floats per LDS row of a chunk of logits (4 * 308 = 16 mod 64 banks)
+
+struct GpWTile {
+  float4 w[4];
+  float bias;
+  int t, off, C, gc;                    // wave-uniform: tile index in its group, the group's column range, group index in the chunk
+};
+
+__device__ __forceinline__ void gp_rowtile16(const GpArgs& p, const float4 (&af)[4], const GpWTile& r, float bias_on, int i, int q,
+                                             int64_t row0, int rt16, float* so, int chunk_off) {
+  const float av[16] = {af[0].x, af[0].y, af[0].z, af[0].w, af[1].x, af[1].y, af[1].z, af[1].w,
+                        af[2].x, af[2].y, af[2].z, af[2].w, af[3].x, af[3].y, af[3].z, af[3].w};
+  const float bv[16] = {r.w[0].x, r.w[0].y, r.w[0].z, r.w[0].w, r.w[1].x, r.w[1].y, r.w[1].z, r.w[1].w,
+                        r.w[2].x, r.w[2].y, r.w[2].z, r.w[2].w, r.w[3].x, r.w[3].y, r.w[3].z, r.w[3].w};
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 16; s += 2) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s + 1], bv[s + 1], acc1, 0, 0, 0);
+  }
+  const int c = 16 * r.t + i;
+  if (so != nullptr) {
+    // the chunk's logits are assembled in LDS (row stride kGpLdO: the four lane groups land 16 banks apart) and leave
+    // the CU as whole row pieces afterwards
+    if (c < r.C) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) so[(rt16 + 4 * q + rr) * kGpLdO + r.off - chunk_off + c] = acc0[rr] + acc1[rr] + bias_on * r.bias;
+    }
+    return;
+  }
+  // A chunk wider than the LDS image: straight to global memory, 64-byte pieces.  Unconditional: a lane past the group's
+  // classes computed class C - 1 again (its weight row was clamped) and a lane past the last row computed the last row
+  // again, so writing to the clamped address repeats a correct value.
+  const int cs = c < r.C ? c : r.C - 1;
+  float* op = p.out + r.off + cs;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    int64_t ro = row0 + rt16 + 4 * q + rr;
+    ro = ro < p.n_rows ? ro : p.n_rows - 1;
+    op[ro * p.ld_out] = acc0[rr] + acc1[rr] + bias_on * r.bias;
+  }
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gproj_fwd_rows(GpArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * 64;
+  const int i = lane & 15, q = lane >> 4;
+  __shared__ __attribute__((aligned(16))) float sA[64 * kGpLdA];
+  __shared__ float sO[64 * kGpLdO];
+  __shared__ uint32_t s_tiles[8][kGpMaxTiles16];
+  // group table in lanes (lane g: group g's column range, the flat index of its first 16-class tile) and the flat tile
+  // list (group | tile << 8) in this wave's LDS slice
+  const int gl = lane < p.G ? lane : p.G - 1;
+  const int c0 = p.seg_off[gl], c1 = p.seg_off[gl + 1];
+  const int my_nt = lane < p.G ? ((c1 - c0 + 15) >> 4) : 0;
+  int start = 0, T = 0;
+  for (int g = 0; g < p.G; ++g) {
+    start = lane == g ? T : start;
+    T += __builtin_amdgcn_readlane(my_nt, g);
+  }
+  start = lane < p.G ? start : T;                      // lanes >= G: "one past the last tile"
+  for (int t = 0; t < my_nt; ++t) s_tiles[wave][start + t] = static_cast<uint32_t>(lane) | (static_cast<uint32_t>(t) << 8);
+  const int n_chunks = (p.G + 3) >> 2;
+  const float* bias_p = p.b != nullptr ? p.b : p.w;      // no bias: any readable address (the value is multiplied by 0)
+  const float bias_on = p.b != nullptr ? 1.f : 0.f;
+  const int width = p.G * 64;
+  // ---- chunk staging: wave w owns rows 8w .. 8w + 7 of the block, lane l columns 4l .. 4l + 3 of the chunk
+  float4 st0, st1, st2, st3, st4, st5, st6, st7;       // named registers (an array captured by a lambda stays in scratch)
+#define GP_ST_LOAD1(r, c_)                                                                        \
+  {                                                                                               \
+    int64_t row_ = row0 + 8 * wave + (r);                                                         \
+    row_ = row_ < p.n_rows ? row_ : p.n_rows - 1;                                                 \
+    st##r = *reinterpret_cast<const float4*>(p.a + row_ * p.ld_a + (c_));                         \
+  }
+#define GP_STAGE_LOAD(c)                                                                          \
+  {                                                                                               \
+    const int col_ = 256 * (c) + 4 * lane;                                                        \
+    const int cc_ = col_ < width ? col_ : width - 4; /* a narrower last chunk repeats a valid piece */ \
+    GP_ST_LOAD1(0, cc_) GP_ST_LOAD1(1, cc_) GP_ST_LOAD1(2, cc_) GP_ST_LOAD1(3, cc_)               \
+    GP_ST_LOAD1(4, cc_) GP_ST_LOAD1(5, cc_) GP_ST_LOAD1(6, cc_) GP_ST_LOAD1(7, cc_)               \
+  }
+#define GP_ST_WRITE1(r, buf) *reinterpret_cast<float4*>(&sA[(8 * wave + (r)) * kGpLdA + 4 * lane]) = st##r;
+#define GP_STAGE_WRITE(buf)                                                                       \
+  {                                                                                               \
+    GP_ST_WRITE1(0, buf) GP_ST_WRITE1(1, buf) GP_ST_WRITE1(2, buf) GP_ST_WRITE1(3, buf)           \
+    GP_ST_WRITE1(4, buf) GP_ST_WRITE1(5, buf) GP_ST_WRITE1(6, buf) GP_ST_WRITE1(7, buf)           \
+  }
+  // ---- this wave's tiles: chunk c owns the flat tiles of groups 4c .. 4c + 3; wave w takes every 8th of them
+  auto chunk_begin = [&](int c) { return __builtin_amdgcn_readlane(start, 4 * c < 63 ? 4 * c : 63); };
+  int nc = 0, nn = chunk_begin(0) + wave;              // the next tile to fetch weights for: chunk, flat index
+  auto settle = [&]() {                                 // move (nc, nn) forward to the wave's next existing tile
+    while (nc < n_chunks && nn >= chunk_begin(nc + 1)) {
+      ++nc;
+      nn = chunk_begin(nc) + wave;
+    }
+  };
+  GpWTile wA, wB;
+  wA.t = wB.t = 0; wA.off = wB.off = 0; wA.C = wB.C = 1; wA.gc = wB.gc = 0;
+  auto fetch_w = [&](GpWTile& o) {                      // weights of tile nn (if any); then advance
+    const uint32_t ds = s_tiles[wave][nn < T ? nn : T - 1];
+    const int g = __builtin_amdgcn_readfirstlane(static_cast<int>(ds & 0xffu));
+    o.t = __builtin_amdgcn_readfirstlane(static_cast<int>(ds >> 8));
+    o.off = __builtin_amdgcn_readlane(c0, g);
+    o.C = __builtin_amdgcn_readlane(c1, g) - o.off;
+    o.gc = g & 3;
+    const int c_ = 16 * o.t + i;
+    const int cc_ = c_ < o.C ? c_ : o.C - 1;
+    const float4* wp = reinterpret_cast<const float4*>(p.w + static_cast<int64_t>(o.off + cc_) * 64 + 4 * q);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) o.w[u] = wp[4 * u];
+    o.bias = bias_p[o.off + cc_];
+    nn += 8;
+    settle();
+  };
+  GP_STAGE_LOAD(0)
+  settle();
+  int cur_c = nc, cur_n = nn;                          // the tile whose weights sit in wA
+  fetch_w(wA);
+  GP_STAGE_WRITE(0)
+  __syncthreads();
+  for (int c = 0; c < n_chunks; ++c) {
+    if (c + 1 < n_chunks) GP_STAGE_LOAD(c + 1)
+    const float* sa = sA;
+    const int chunk_off = __builtin_amdgcn_readlane(c0, 4 * c), g_end = 4 * c + 4 < p.G ? 4 * c + 4 : p.G;
+    const int chunk_w = __builtin_amdgcn_readlane(c1, g_end - 1) - chunk_off;
+    float* so = chunk_w <= kGpLdO ? sO : nullptr;
+    // tiles of this chunk that are this wave's, two per trip (the weight register sets alternate)
+    while (cur_c == c && cur_n < T) {
+      int nxt_c = nc, nxt_n = nn;
+      fetch_w(wB);
+      {
+        float4 af[4][4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            af[rt][u] = *reinterpret_cast<const float4*>(&sa[(16 * rt + i) * kGpLdA + wA.gc * 64 + 16 * u + 4 * q]);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) gp_rowtile16(p, af[rt], wA, bias_on, i, q, row0, 16 * rt, so, chunk_off);
+      }
+      cur_c = nxt_c; cur_n = nxt_n;
+      if (!(cur_c == c && cur_n < T)) {                  // the tile in wB belongs to a later chunk: keep it as wA
+        wA = wB;
+        break;
+      }
+      nxt_c = nc; nxt_n = nn;
+      fetch_w(wA);
+      {
+        float4 af[4][4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            af[rt][u] = *reinterpret_cast<const float4*>(&sa[(16 * rt + i) * kGpLdA + wB.gc * 64 + 16 * u + 4 * q]);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) gp_rowtile16(p, af[rt], wB, bias_on, i, q, row0, 16 * rt, so, chunk_off);
+      }
+      cur_c = nxt_c; cur_n = nxt_n;
+    }
+    __syncthreads();                                   // every tile of the chunk is done: sO complete, sA free
+    if (c + 1 < n_chunks) GP_STAGE_WRITE(0)
+    if (so != nullptr) {                                // whole row pieces: 256 contiguous bytes per store instruction
+      for (int r = 0; r < 8; ++r) {
+        const int64_t ro = row0 + 8 * wave + r;
+        if (ro >= p.n_rows) break;
+        for (int col = lane; col < chunk_w; col += 64) p.out[ro * p.ld_out + chunk_off + col] = so[(8 * wave + r) * kGpLdO + col];
+      }
+    }
+    __syncthreads();                                   // sA holds chunk c + 1, sO may be overwritten
+  }
+#undef GP_ST_LOAD1
+#undef GP_STAGE_LOAD
+#undef GP_ST_WRITE1
+#undef GP_STAGE_WRITE
 }
 
 template <int K>
@@ -222,6 +425,15 @@ __global__ __launch_bounds__(256) void k_gproj_dw(GpArgs p) {
   }
 }
 
+// A/B switch for scripts/bench_gproj.py: AGNN_GPROJ_FWD=1 -> the one-group-per-workgroup kernel instead of the whole-row one
+int flags_fwd_variant() {
+  static const int v = [] {
+    const char* e = getenv("AGNN_GPROJ_FWD");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
 struct Plan { int S, rows_per_slice; };
 
 Plan make_plan(int64_t n, int n_tiles32) {
@@ -264,6 +476,10 @@ extern "C" int agnn_gproj_fwd_f32(const float* a, int64_t ld_a, const float* w, 
   p.ld_a = ld_a; p.ld_out = ld_out; p.n_rows = n_rows; p.G = n_groups;
   p.n_row_tiles = static_cast<int32_t>((n_rows + 31) / 32);
   hipStream_t s = static_cast<hipStream_t>(stream_);
+  if (K == 64 && n_groups <= 32 && n_tiles32 <= kGpMaxTiles16 / 2 && flags_fwd_variant() != 1) {   // whole-row kernel
+    hipLaunchKernelGGL(k_gproj_fwd_rows, dim3(static_cast<unsigned>((n_rows + 63) / 64)), dim3(512), 0, s, p);
+    return check_launch("gproj_fwd(rows)");
+  }
   const int64_t row_blocks = (n_rows + 127) / 128;
   const dim3 grid(static_cast<unsigned>(row_blocks * n_groups));
   if (K == 32) hipLaunchKernelGGL(k_gproj_fwd<32>, grid, dim3(256), 0, s, p);
