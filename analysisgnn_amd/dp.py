@@ -213,6 +213,13 @@ def enable_wgrad_overlap(flag: bool = True, scope: str = "all") -> None:
     linear.enable_wgrad_overlap(flag, scope)
 
 
+def defer_weight_grads(flag: bool = True) -> None:
+    """Weight / bias gradients of the projections on the backward pass's own stream are postponed to where that stream
+    would otherwise idle (linear.defer_weight_grads); `FlatGradBuffer.pack` runs whatever is still pending."""
+    from .linear import defer_weight_grads as _set
+    _set(flag)
+
+
 def barrier_and_sync() -> None:
     if dist.is_initialized():
         dist.barrier()

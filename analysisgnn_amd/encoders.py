@@ -33,7 +33,7 @@ from . import _lib, ops
 from .gru import gru_forward
 from .fused import FusedSequential, norm_act
 from .params import sage_operands, sage_operands_cat
-from .linear import Linear, linear
+from .linear import Linear, deferring, flush_deferred, linear
 from .core_layers import JumpingKnowledge
 from .graph import HeteroIndex, hetero_index
 
@@ -252,6 +252,22 @@ def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
     return _SIDE_STREAMS[idx]
 
 
+class _FlushPoint(torch.autograd.Function):
+    """Identity on a branch's input.  Its backward runs where the branch's backward ends, and runs the weight gradients that
+    the backward pass has deferred ON THIS STREAM so far (linear.defer_weight_grads) right there: for the GNN stack that is
+    where the main stream starts to idle until the sequence branch's backward arrives; for the sequence branch, behind the
+    last dX of the recurrence — beside the input projection's backward instead of ahead of the recurrence."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        flush_deferred()
+        return g
+
+
 class _HybridMixin:
     def _init_hybrid(self, input_channels, hidden_channels, num_layers, dropout, use_jk):
         self.use_jk = bool(use_jk)
@@ -298,8 +314,20 @@ class _HybridMixin:
         side = _side_stream(dev)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            z = self.hybrid_forward(_head(x_in, batch_size), batch_note)
+            x_seq = _head(x_in, batch_size)
+            if torch.is_grad_enabled() and x_seq.requires_grad and deferring(x_seq):
+                x_seq = _FlushPoint.apply(x_seq)         # the branch's own deferred weight gradients follow its last dX
+            z = self.hybrid_forward(x_seq, batch_note)
         return z, side
+
+    @staticmethod
+    def _gnn_input(x_dict, side):
+        """The GNN stack's input; with deferred weight gradients and a sequence branch running beside the stack, the note
+        matrix passes through the flush point (see _FlushPoint)."""
+        x = x_dict["note"]
+        if side is None or not (torch.is_grad_enabled() and x.requires_grad and deferring(x)):
+            return x_dict
+        return {**x_dict, "note": _FlushPoint.apply(x)}
 
     def _finish(self, x_note, outs, z, side, batch_size):
         x = _head(x_note, batch_size)
@@ -336,7 +364,7 @@ class HybridGNN(nn.Module, _HybridMixin):
         plan = TrimPlan(self.num_layers, x_dict, edge_index_dict, neighbor_mask_node, neighbor_mask_edge)
         outs: list = []
         z, side = self._start_branch(x_dict["note"], batch_dict, batch_size)
-        h = self.gnn(x_dict, edge_index_dict, plan, outs)
+        h = self.gnn(self._gnn_input(x_dict, side), edge_index_dict, plan, outs)
         out = self._finish(h["note"], outs, z, side, batch_size)
         return (out, edge_index_dict) if return_edge_index else out
 

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .fused import grouped_norm_act
-from .linear import linear, mark_wgrad_async, wgrad_stream
+from .linear import defer, deferring, linear, mark_wgrad_async, wgrad_stream
 from .params import cat_rows, stack_rows
 
 
@@ -32,8 +32,8 @@ def fused_head_logits(clf_dict: nn.ModuleDict, x: torch.Tensor, tasks: Sequence[
     h2 = mods[0][0].out_features
     # cat / stack of leaf parameters: their backward is narrow / unbind (views), so these gradients may arrive late;
     # the cats themselves are views when the parameters are adjacent in memory (dp.plan_parameters), launches otherwise
-    W1 = mark_wgrad_async(cat_rows([m[0].weight for m in mods]))          # [T*h2, o]
-    b1 = mark_wgrad_async(cat_rows([m[0].bias for m in mods]))
+    W1 = mark_wgrad_async(cat_rows([m[0].weight for m in mods]), deferrable=True)          # [T*h2, o]; the cat's backward only takes views
+    b1 = mark_wgrad_async(cat_rows([m[0].bias for m in mods]), deferrable=True)
     a = linear(x, W1, b1)                                                 # [N, T*h2]
     gamma = stack_rows([m[2].weight for m in mods])                       # [T, h2]
     beta = stack_rows([m[2].bias for m in mods])
@@ -44,8 +44,8 @@ def fused_head_logits(clf_dict: nn.ModuleDict, x: torch.Tensor, tasks: Sequence[
     b2 = cat_rows([m[3].bias for m in mods])
     a = a.reshape(-1, T * h2)
     if a.is_cuda and h2 in GPROJ_K and T <= _lib.MAX_SEG and GPROJ_ENABLED:
-        W2 = mark_wgrad_async(cat_rows([m[3].weight for m in mods]))           # [sum C, h2]
-        logits = grouped_projection(a, W2, mark_wgrad_async(b2), offs, h2)
+        W2 = mark_wgrad_async(cat_rows([m[3].weight for m in mods]), deferrable=True)           # [sum C, h2]
+        logits = grouped_projection(a, W2, mark_wgrad_async(b2, deferrable=True), offs, h2)
     else:                                                                 # widths the kernel is not built for
         W2 = torch.block_diag(*[m[3].weight for m in mods])               # [sum C, T*h2]
         logits = linear(a, W2, b2)
@@ -69,6 +69,7 @@ class _GroupedProj(torch.autograd.Function):
     def forward(ctx, a, w, b, offs_t, offs, K):
         dev = _lib.require_gpu(a, w, offs_t)
         ctx._wg_async_in = all(t is None or t.is_leaf or getattr(t, "_agnn_wgrad_async", False) for t in (w, b))
+        ctx._wg_defer_in = all(t is None or t.is_leaf or getattr(t, "_agnn_wgrad_deferrable", False) for t in (w, b))
         a = _lib.f32c(a)
         w = _lib.f32c(w)
         if w.data_ptr() % 16:
@@ -85,6 +86,7 @@ class _GroupedProj(torch.autograd.Function):
         ctx.save_for_backward(a, w, offs_t)
         ctx.meta = (G, K, tiles, sum_c, b is not None)
         ctx.wg_async = ctx._wg_async_in
+        ctx.wg_defer = ctx._wg_defer_in
         return out
 
     @staticmethod
@@ -97,15 +99,22 @@ class _GroupedProj(torch.autograd.Function):
         lib = _lib.load()
         need_w = ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2])
         dw = db = None
-        if need_w:                                   # optimizer-only outputs: weight-gradient stream (linear.py)
-            with wgrad_stream(dev, dout, a, active=ctx.wg_async):
-                dw = torch.empty_like(w)
-                db = torch.empty((sum_c,), dtype=torch.float32, device=dev) if has_b else None
+        if need_w:                                   # optimizer-only outputs: deferred, or on the weight-gradient stream (linear.py)
+            dw = torch.empty_like(w)
+            db = torch.empty((sum_c,), dtype=torch.float32, device=dev) if has_b else None
+            dw_k, db_k = dw.detach(), (db.detach() if db is not None else None)     # aliases: see linear._LinearFn.backward
+
+            def weight_grads():
                 nws = int(lib.agnn_gproj_workspace_bytes(N, sum_c, K, tiles))
                 ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=dev)
                 _lib.check(lib.agnn_gproj_bwd_f32(dout.data_ptr(), dout.stride(0), a.data_ptr(), a.stride(0), w.data_ptr(),
-                                                  offs_t.data_ptr(), G, K, tiles, sum_c, N, None, 0, dw.data_ptr(), _lib.ptr(db),
+                                                  offs_t.data_ptr(), G, K, tiles, sum_c, N, None, 0, dw_k.data_ptr(), _lib.ptr(db_k),
                                                   ws.data_ptr(), nws, _lib.stream_ptr(dev)), "agnn_gproj_bwd_f32")
+            if ctx.wg_async and ctx.wg_defer and deferring(dout):
+                defer(weight_grads, dev)
+            else:
+                with wgrad_stream(dev, dout, a, dw_k, db_k, active=ctx.wg_async):
+                    weight_grads()
         da = None
         if ctx.needs_input_grad[0]:
             da = torch.empty_like(a)

@@ -686,7 +686,7 @@ class HybridHGT(nn.Module, _HybridMixin):
         plan = TrimPlan(self.num_layers, x_dict, edge_index_dict, neighbor_mask_node, neighbor_mask_edge)
         outs: list = []
         z, side = self._start_branch(x_dict["note"], batch_dict, batch_size)
-        h = self.gnn(x_dict, edge_index_dict, plan, outs)
+        h = self.gnn(self._gnn_input(x_dict, side), edge_index_dict, plan, outs)
         out = self._finish(h["note"], outs, z, side, batch_size)
         return (out, edge_index_dict) if return_edge_index else out
 

@@ -39,10 +39,17 @@ def wgrad_overlap_enabled() -> bool:
     return _WG["enabled"]
 
 
-def mark_wgrad_async(t: torch.Tensor) -> torch.Tensor:
-    """Declare that the gradient of this (non-leaf) operand is consumed without kernels on the launching stream."""
+def mark_wgrad_async(t: torch.Tensor, deferrable: bool = False) -> torch.Tensor:
+    """Declare that the gradient of this (non-leaf) operand is consumed without kernels on the launching stream.
+    `deferrable`: it may also be produced LATER than the backward pass reaches its consumer (defer_weight_grads) — true when
+    the consumer only takes views of it, or defers its own kernels behind it."""
     t._agnn_wgrad_async = True
+    t._agnn_wgrad_deferrable = bool(deferrable)
     return t
+
+
+def _deferrable(t: Optional[torch.Tensor]) -> bool:
+    return t is None or t.is_leaf or getattr(t, "_agnn_wgrad_deferrable", False)
 
 
 def _async_ok(t: Optional[torch.Tensor]) -> bool:
@@ -89,8 +96,59 @@ class wgrad_stream:
         return False
 
 
+# ------------------------------------------------------------------------------------------------------------
+# Deferred weight gradients.  On the stream that carries the backward pass, dW / db of a projection sit between its dX
+# and the next layer's backward although only the optimizer reads them; in the hybrid encoders that stream later IDLES
+# (~0.7 ms at C2) until the sequence branch's backward has finished (profiles/r02_step_timeline.md).  With
+# `defer_weight_grads(True)` a projection's backward leaves a closure instead of launching dW / db; the closures run, in
+# order, on the same stream at `flush_deferred()` — the hybrid encoders call it where the GNN stack's backward ends, i.e.
+# at the start of that idle window — and, for whatever is still pending, in `join_wgrad()` before the gradients are
+# gathered.  No second stream, no fork: inside a replayed hipGraph a fork delays whichever chain is captured second.
+# Only for gradients that autograd takes over without a kernel (`_steals`).  Closures are kept per stream and run on the
+# stream that deferred them (their operands were produced there).
+# ------------------------------------------------------------------------------------------------------------
+_DEFER = {"on": False, "pending": {}}        # pending: (device index, stream handle) -> (stream, [closures])
+
+
+def defer_weight_grads(flag: bool = True) -> None:
+    _DEFER["on"] = bool(flag)
+    if not flag:
+        flush_all_deferred()
+
+
+def deferring(t: torch.Tensor) -> bool:
+    return bool(_DEFER["on"] and t.is_cuda)
+
+
+def defer(fn, dev) -> None:
+    s = torch.cuda.current_stream(dev)
+    _DEFER["pending"].setdefault((s.device.index, s.cuda_stream), (s, []))[1].append(fn)
+
+
+def flush_deferred(dev=None) -> None:
+    """Run, on the current stream, the closures that were deferred on it."""
+    s = torch.cuda.current_stream(dev)
+    entry = _DEFER["pending"].pop((s.device.index, s.cuda_stream), None)
+    if entry is not None:
+        for fn in entry[1]:
+            fn()
+
+
+def flush_all_deferred() -> None:
+    """Every stream's pending closures, each list on its own stream; the current stream then waits for the others."""
+    cur = torch.cuda.current_stream() if torch.cuda.is_available() else None
+    for key in list(_DEFER["pending"]):
+        s, fns = _DEFER["pending"].pop(key)
+        with torch.cuda.stream(s):
+            for fn in fns:
+                fn()
+        if cur is not None and (s.device.index, s.cuda_stream) != (cur.device.index, cur.cuda_stream):
+            torch.cuda.current_stream(s.device).wait_stream(s)
+
+
 def join_wgrad() -> None:
     """Make the current stream wait for all weight-gradient work issued so far (no host sync)."""
+    flush_all_deferred()
     for idx in list(_WG["dirty"]):
         torch.cuda.current_stream(idx).wait_stream(_WG["streams"][idx])
     _WG["dirty"].clear()
@@ -147,6 +205,7 @@ class _LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         ctx.wg_async = _async_ok(w) and _async_ok(b)
+        ctx.wg_defer = _deferrable(w) and _deferrable(b)
         ctx.b_ref = b if (b is not None and b.is_leaf) else None
         ctx.set_materialize_grads(False)          # an undefined output gradient (a structurally dead branch) stays undefined upstream
         if acc is not None:                       # y = acc + x W^T (+ b): the GEMM's beta = 1 epilogue, no separate add
@@ -160,10 +219,20 @@ class _LinearFn(torch.autograd.Function):
             return None, None, None, None
         x, w = ctx.saved_tensors
         dw = db = None
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        steals = ctx.wg_async and _steals(w) and _steals(ctx.b_ref)     # gradients taken over without a kernel on this stream
+        if want_w and steals and ctx.wg_defer and x.shape[1] % 2 == 0 and deferring(dy):
+            # only dX stays here.  The closure fills aliases: a second reference to `dw` itself would make AccumulateGrad
+            # CLONE it (now, before it is computed) instead of taking it over.
+            dw = torch.empty((dy.shape[1], x.shape[1]), dtype=torch.float32, device=dy.device)
+            db = torch.empty((dy.shape[1],), dtype=torch.float32, device=dy.device) if want_b else None
+            dw_k, db_k = dw.detach(), (db.detach() if db is not None else None)
+            defer(lambda: weight_grad(dy, x, want_b, dw_out=dw_k, db_out=db_k), dy.device)
+        elif want_w:
             # forked before dX is queued: both start at once — only when the gradients will be STOLEN (no kernel on the main stream)
-            with wgrad_stream(dy.device, dy, x, active=ctx.wg_async and _steals(w) and _steals(ctx.b_ref)):
-                dw, db = weight_grad(dy, x, ctx.has_bias and ctx.needs_input_grad[2])
+            with wgrad_stream(dy.device, dy, x, active=steals):
+                dw, db = weight_grad(dy, x, want_b)
         dx = dy @ w if ctx.needs_input_grad[0] else None
         return dx, dw, db, (dy if ctx.needs_input_grad[3] else None)
 

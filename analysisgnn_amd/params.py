@@ -12,7 +12,7 @@ from typing import List, Sequence, Tuple
 import torch
 
 from . import _lib
-from .linear import mark_wgrad_async, wgrad_stream
+from .linear import defer, deferring, mark_wgrad_async, wgrad_stream
 
 
 def pack(items: Sequence[Tuple[torch.Tensor, Sequence[torch.Tensor]]], device) -> None:
@@ -66,15 +66,21 @@ class _SageOperands(torch.autograd.Function):
         G_l = torch.empty((R, out_f, in_f), dtype=torch.float32, device=dev)
         G_b = torch.empty((R, out_f), dtype=torch.float32, device=dev)
         G_r = torch.empty((R, out_f, in_f), dtype=torch.float32, device=dev)
-        # the incoming gradients may have been produced on the weight-gradient stream: fan them out there as well
-        with wgrad_stream(dev, dW_l, db, dW_r, active=ctx.leaves):
-            dW_l, db, dW_r = _lib.f32c(dW_l), db.contiguous(), _lib.f32c(dW_r)
+        def fan_out():
+            dW_l_, db_, dW_r_ = _lib.f32c(dW_l), db.contiguous(), _lib.f32c(dW_r)
             items = []
             for r in range(R):
-                items.append((G_l[r], [dW_l[:, r * in_f:(r + 1) * in_f]]))
-                items.append((G_b[r].view(1, -1), [db.view(1, -1)]))
-                items.append((G_r[r], [dW_r]))
+                items.append((G_l[r], [dW_l_[:, r * in_f:(r + 1) * in_f]]))
+                items.append((G_b[r].view(1, -1), [db_.view(1, -1)]))
+                items.append((G_r[r], [dW_r_]))
             pack(items, dev)
+        # the incoming gradients may be deferred (linear.defer_weight_grads: they do not exist yet — fan them out behind
+        # them) or produced on the weight-gradient stream (fan them out there as well)
+        if ctx.leaves and deferring(dW_l):
+            defer(fan_out, dev)
+        else:
+            with wgrad_stream(dev, dW_l, db, dW_r, active=ctx.leaves):
+                fan_out()
         # unbind: one contiguous tensor per parameter (distinct memory, so each .grad can be taken over as is)
         return (None, *G_l.unbind(0), *G_b.unbind(0), *G_r.unbind(0))
 
@@ -109,17 +115,23 @@ class _SageOperandsCat(torch.autograd.Function):
         G_l = torch.empty((nl, out_f, in_f), dtype=torch.float32, device=dev)
         G_b = torch.empty((R, out_f), dtype=torch.float32, device=dev)
         G_r = torch.empty((R, out_f, in_f), dtype=torch.float32, device=dev)
-        with wgrad_stream(dev, dW, db, active=ctx.leaves):
-            dW, db = _lib.f32c(dW), db.contiguous()
+        if not nl:    # unused this step, yet still a parameter of the step: a zero gradient (as the reference's zeros @ W gives), not None
+            G_l = torch.zeros((R, out_f, in_f), dtype=torch.float32, device=dev)
+
+        def fan_out():
+            dW_, db_ = _lib.f32c(dW), db.contiguous()
             items = []
             for r in range(R):
                 if r < nl:
-                    items.append((G_l[r], [dW[:, r * in_f:(r + 1) * in_f]]))
-                items.append((G_b[r].view(1, -1), [db.view(1, -1)]))
-                items.append((G_r[r], [dW[:, nl * in_f:]]))
+                    items.append((G_l[r], [dW_[:, r * in_f:(r + 1) * in_f]]))
+                items.append((G_b[r].view(1, -1), [db_.view(1, -1)]))
+                items.append((G_r[r], [dW_[:, nl * in_f:]]))
             pack(items, dev)
-        if not nl:    # unused this step, yet still a parameter of the step: a zero gradient (as the reference's zeros @ W gives), not None
-            G_l = torch.zeros((R, out_f, in_f), dtype=torch.float32, device=dev)
+        if ctx.leaves and deferring(dW):     # the incoming gradients are deferred too: fan them out behind them (see above)
+            defer(fan_out, dev)
+        else:
+            with wgrad_stream(dev, dW, db, active=ctx.leaves):
+                fan_out()
         return (None, None, *G_l.unbind(0), *G_b.unbind(0), *G_r.unbind(0))
 
 
@@ -134,7 +146,7 @@ def sage_operands_cat(w_l: List[torch.Tensor], b_l: List[torch.Tensor], w_r: Lis
     ops_ = _SageOperandsCat.apply(R, with_l, *w_l, *b_l, *w_r)
     if all(t.is_leaf for t in (*w_l, *b_l, *w_r)):
         for t in ops_:
-            mark_wgrad_async(t)
+            mark_wgrad_async(t, deferrable=True)        # the fan-out defers itself behind a deferred gradient
     return ops_
 
 
@@ -147,7 +159,7 @@ def sage_operands(w_l: List[torch.Tensor], b_l: List[torch.Tensor], w_r: List[to
     ops_ = _SageOperands.apply(R, *w_l, *b_l, *w_r)
     if all(t.is_leaf for t in (*w_l, *b_l, *w_r)):
         for t in ops_:
-            mark_wgrad_async(t)
+            mark_wgrad_async(t, deferrable=True)
     return ops_
 
 

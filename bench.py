@@ -69,6 +69,7 @@ def parse_args(argv=None):
     ap.add_argument("--mt-strategy", default="wloss", choices=["wloss", "sum"],
                     help="wloss (reference CLI default): learned uncertainty weights per task; sum: plain sum of the task losses")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying hipGraphs")
+    ap.add_argument("--no-defer", action="store_true", help="A/B only: weight gradients where they are computed, not deferred")
     ap.add_argument("--no-wgrad-overlap", action="store_true", help="A/B only: weight gradients on the main stream")
     ap.add_argument("--library-wgrad", action="store_true", help="A/B only: weight gradients through the library GEMM")
     ap.add_argument("--blas", default=None, choices=[None, "hipblaslt", "rocblas"], help="A/B only: torch's preferred BLAS library")
@@ -261,6 +262,9 @@ def main():
     # the GRU layers' weight-gradient work on its own stream, joined in flat.pack() — only where the sequence branch is
     # the longer one (C2; with HGT / MetricalGNN the graph branch is, and the extra stream only adds contention)
     dp.enable_wgrad_overlap(not args.no_wgrad_overlap and args.workload in ("c2", "c2s"), "sequence")
+    # dW / db of the projections on the main stream wait until that stream has slack (the GNN stack's backward is done, the
+    # sequence branch's is not): the hybrid encoders only
+    dp.defer_weight_grads(not args.no_defer and enc in ("hybridgnn", "hgt"))
     opt = dp.FlatAdamW(params, flat, lr=5e-3, weight_decay=5e-3)     # analysis.py:1380-1381 hyper-parameters
     graph.index_cache_enabled = False                               # fresh batch every step: rebuild the CSR
 
@@ -315,6 +319,14 @@ def main():
         if sampler is not None:                                     # the loader's only host-side decision: which windows (32 int32 H2D)
             sampler.set_windows(store.random_windows(N_SUB, N_NOTES, win_rng))
         if graphs is not None:
+            if HOST_T is not None:
+                h0 = time.perf_counter()
+                graphs[0].replay()
+                h1 = time.perf_counter()
+                flat.all_reduce_mean()
+                graphs[1].replay()
+                HOST_T.append((h1 - h0, time.perf_counter() - h1))
+                return loss_ref[0]
             graphs[0].replay()
             flat.all_reduce_mean()
             graphs[1].replay()
@@ -324,6 +336,7 @@ def main():
         update()
         return loss
 
+    HOST_T = [] if os.environ.get("AGNN_HOST_TIMES") else None     # debugging: host time inside the two replay calls of a step
     for _ in range(args.warmup):
         step()
     dp.barrier_and_sync()
@@ -333,6 +346,11 @@ def main():
     dp.barrier_and_sync()
     dt = time.perf_counter() - t0
     dt = dp.max_over_ranks(dt)
+    if HOST_T:
+        a = sorted(t[0] for t in HOST_T[args.warmup:])
+        b = sorted(t[1] for t in HOST_T[args.warmup:])
+        print(f"[bench] host time in replay calls: step graph median {a[len(a) // 2] * 1e6:.0f} us (max {a[-1] * 1e6:.0f}), "
+              f"update graph median {b[len(b) // 2] * 1e6:.0f} us; wall per step {dt / args.steps * 1e6:.0f} us", file=sys.stderr)
     assert torch.isfinite(loss).item(), "loss diverged"
     from analysisgnn_amd import _lib
     _lib.check_device_status(dev)                      # no CSR build of the run flagged an inconsistent index (outside the timed region)

@@ -7,7 +7,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_graph_replay_equals_eager_step_and_is_reproducible():
+@pytest.mark.parametrize("defer", [False, True])
+def test_graph_replay_equals_eager_step_and_is_reproducible(defer):
+    """`defer`: the projections' weight gradients leave their place in the backward pass and run at the flush points of the
+    hybrid encoder (dp.defer_weight_grads) — the same kernels on the same operands, so the gradients must not change by a bit
+    (checked against the undeferred eager step)."""
     from analysisgnn_amd import dp, graph
     from analysisgnn_amd.heads import multitask_cross_entropy
     from analysisgnn_amd.models import TorchAnalysisGNN
@@ -44,6 +48,13 @@ def test_graph_replay_equals_eager_step_and_is_reproducible():
         torch.cuda.synchronize()
         g_eager, l_eager = flat.flat.clone(), float(loss_e)
         assert torch.isfinite(g_eager).all() and float(g_eager.abs().max()) > 0
+        if defer:
+            dp.defer_weight_grads(True)
+            with torch.cuda.stream(side):
+                loss_d = fwd_bwd()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize()
+            assert float(loss_d) == l_eager and torch.equal(flat.flat, g_eager)
         cg = torch.cuda.CUDAGraph()
         with torch.cuda.graph(cg):
             loss_g = fwd_bwd()
@@ -60,6 +71,7 @@ def test_graph_replay_equals_eager_step_and_is_reproducible():
         assert torch.equal(g1, g2)
     finally:
         dp.enable_wgrad_overlap(False)
+        dp.defer_weight_grads(False)
         graph.index_cache_enabled = was
 
 
