@@ -22,6 +22,8 @@ here has a CPU path.
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -243,6 +245,9 @@ def _head(t: torch.Tensor, n: int) -> torch.Tensor:
 
 
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+# A/B switch: issue the sequence branch AFTER the GNN stack (it still forks where the input is ready).  The autograd engine
+# runs ready nodes newest-first, so the branch issued last in the forward pass is differentiated — and captured — first.
+SEQUENCE_BRANCH_LAST = os.environ.get("AGNN_SEQ_LAST", "0") == "1"
 
 
 def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
@@ -253,10 +258,9 @@ def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
 
 
 class _FlushPoint(torch.autograd.Function):
-    """Identity on a branch's input.  Its backward runs where the branch's backward ends, and runs the weight gradients that
-    the backward pass has deferred ON THIS STREAM so far (linear.defer_weight_grads) right there: for the GNN stack that is
-    where the main stream starts to idle until the sequence branch's backward arrives; for the sequence branch, behind the
-    last dX of the recurrence — beside the input projection's backward instead of ahead of the recurrence."""
+    """Identity on the GNN stack's input.  Its backward runs where the stack's backward ends — where the main stream starts
+    to idle until the sequence branch's backward arrives — and runs the weight gradients that the backward pass has deferred
+    on this stream so far (linear.defer_weight_grads) right there."""
 
     @staticmethod
     def forward(ctx, x):
@@ -266,6 +270,33 @@ class _FlushPoint(torch.autograd.Function):
     def backward(ctx, g):
         flush_deferred()
         return g
+
+
+class _ForkInput(torch.autograd.Function):
+    """The encoder input handed to both branches: (x for the GNN stack, x[:n] for the sequence branch).  Its backward IS the
+    join of the two backward passes: the sequence branch's input gradient is added onto the first n rows of the GNN stack's
+    (one launch over n rows, on the main stream), instead of autograd's SliceBackward (a full-size zero fill and a copy, on
+    the branch's stream — as late dependents of the recurrence's last GEMM they started ~0.18 ms after it in the replayed
+    graph) plus a full-size gradient add.  Only then — captured after the join, so that the join is the first dependent of
+    that GEMM — the sequence branch's deferred weight gradients are issued on its own stream."""
+
+    @staticmethod
+    def forward(ctx, x, n, side):
+        ctx.n, ctx.side = n, side
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), x.narrow(0, 0, n)
+
+    @staticmethod
+    def backward(ctx, g_gnn, g_seq):
+        g = g_gnn
+        if g_seq is not None:
+            if g is None:
+                raise _lib.AgnnError("_ForkInput: the GNN stack produced no input gradient")   # both branches read the input
+            g[:ctx.n] += g_seq                       # in place: the GNN stack's gradient is this node's alone
+        if ctx.side is not None:
+            with torch.cuda.stream(ctx.side):
+                flush_deferred(g.device if g is not None else None)
+        return g, None, None
 
 
 class _HybridMixin:
@@ -312,27 +343,33 @@ class _HybridMixin:
             return self.hybrid_forward(_head(x_in, batch_size), batch_note), None
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev)
+        self._gnn_note = None
+        x_seq = None
+        if torch.is_grad_enabled() and x_in.requires_grad and deferring(x_in):
+            # deferred weight gradients: the two branches hang off one node whose backward is their join (_ForkInput), and the
+            # GNN stack's input passes through the main stream's flush point (_FlushPoint)
+            x_gnn, x_seq = _ForkInput.apply(x_in, batch_size, side)
+            self._gnn_note = _FlushPoint.apply(x_gnn)
         side.wait_stream(main)
-        with torch.cuda.stream(side):
-            x_seq = _head(x_in, batch_size)
-            if torch.is_grad_enabled() and x_seq.requires_grad and deferring(x_seq):
-                x_seq = _FlushPoint.apply(x_seq)         # the branch's own deferred weight gradients follow its last dX
-            z = self.hybrid_forward(x_seq, batch_note)
-        return z, side
 
-    @staticmethod
-    def _gnn_input(x_dict, side):
-        """The GNN stack's input; with deferred weight gradients and a sequence branch running beside the stack, the note
-        matrix passes through the flush point (see _FlushPoint)."""
-        x = x_dict["note"]
-        if side is None or not (torch.is_grad_enabled() and x.requires_grad and deferring(x)):
-            return x_dict
-        return {**x_dict, "note": _FlushPoint.apply(x)}
+        def branch():
+            with torch.cuda.stream(side):
+                return self.hybrid_forward(x_seq if x_seq is not None else _head(x_in, batch_size), batch_note)
+        if SEQUENCE_BRANCH_LAST:
+            return branch, side                      # issued by `_finish`, behind the GNN stack (A/B switch, see there)
+        return branch(), side
+
+    def _gnn_input(self, x_dict, side):
+        """The GNN stack's input: the dict itself, or (deferred weight gradients) the note matrix behind the flush point."""
+        note, self._gnn_note = getattr(self, "_gnn_note", None), None
+        return x_dict if note is None else {**x_dict, "note": note}
 
     def _finish(self, x_note, outs, z, side, batch_size):
         x = _head(x_note, batch_size)
         if self.use_jk:
             x = self.jk([_head(o, batch_size) for o in outs])
+        if callable(z):
+            z = z()
         if side is not None:
             torch.cuda.current_stream(x.device).wait_stream(side)
             z.record_stream(torch.cuda.current_stream(x.device))

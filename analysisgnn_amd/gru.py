@@ -11,14 +11,15 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .linear import mark_wgrad_async, weight_grad, wgrad_stream
+from .linear import defer, deferring, mark_wgrad_async, weight_grad, wgrad_stream
 
 KERNEL_HIDDEN = 128
 
 
 class _GRULayer(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, last_in_backward=False):
+        ctx.last_in_backward = bool(last_in_backward)
         # x [B,T,I]; w_ih [2,3H,I]; w_hh [2,3H,H]; b_ih, b_hh [2,3H]
         dev = _lib.require_gpu(x, w_ih, w_hh, b_ih, b_hh)
         B, T, I = x.shape
@@ -73,9 +74,17 @@ class _GRULayer(torch.autograd.Function):
             for d in range(2):
                 weight_grad(dgh2[:, d * 3 * Hh:(d + 1) * 3 * Hh], hp2[:, d * Hh:(d + 1) * Hh], True, dw_out=dw_hh[d], db_out=db_hh[d])
 
-        with wgrad_stream(dev, dgi, dgh, y, x2, hp, dw_ih, db_ih, dw_hh, db_hh, active=ctx.wg_async, kind="sequence"):
-            weight_grads()
-        return dx, dw_ih.view(2, 3 * Hh, I), dw_hh, db_ih.view(2, 3 * Hh), db_hh
+        def forked():
+            with wgrad_stream(dev, dgi, dgh, y, x2, hp, dw_ih, db_ih, dw_hh, db_hh, active=ctx.wg_async, kind="sequence"):
+                weight_grads()
+        # The layer whose backward runs last (layer 0) ends the branch: with deferred weight gradients its fork is issued by
+        # the branch's join (encoders._ForkInput), AFTER the join's own kernel — the join is then the first-captured dependent
+        # of this layer's dX GEMM and is not held back by the replayed graph (profiles/r02_step_timeline.md).
+        if ctx.last_in_backward and ctx.wg_async and deferring(dy):
+            defer(forked, dev)
+        else:
+            forked()
+        return dx, dw_ih.view(2, 3 * Hh, I), dw_hh, db_ih.view(2, 3 * Hh), db_hh, None
 
 
 def kernel_applicable(rnn: nn.GRU) -> bool:
@@ -93,7 +102,7 @@ def gru_forward(rnn: nn.GRU, x: torch.Tensor, training: bool) -> torch.Tensor:
     stacked = _stack_gru_params(rnn)
     for layer in range(rnn.num_layers):
         w_ih, w_hh, b_ih, b_hh = stacked[4 * layer:4 * layer + 4]
-        y = _GRULayer.apply(y.contiguous(), w_ih, w_hh, b_ih, b_hh)
+        y = _GRULayer.apply(y.contiguous(), w_ih, w_hh, b_ih, b_hh, layer == 0)
         if layer < rnn.num_layers - 1 and rnn.dropout > 0 and training:
             y = F.dropout(y, rnn.dropout, True)
     return y
