@@ -202,7 +202,9 @@ Plan make_plan(int64_t n, int out_f, int in_f) {
   p.out_pad = p.tiles_out * 128;
   p.in_pad = p.tiles_in * 128;
   const int tiles = p.tiles_out * p.tiles_in;
-  int64_t S = (512 + tiles - 1) / tiles;            // ~2 workgroups per CU
+  // two workgroups per CU, and never a few more than that: rounding the slice count UP gave 520 workgroups for 256 x 1280
+  // (20 tiles x 26 slices) — a third round of 8 workgroups behind two full ones: 147 us instead of the ~110 its FLOPs take
+  int64_t S = 512 / tiles;
   const int64_t max_s = (n + 63) / 64;              // at least 64 rows per slice
   if (S > max_s) S = max_s;
   if (S > 64) S = 64;                               // slab traffic: S * out * in * 4 B written and read back
