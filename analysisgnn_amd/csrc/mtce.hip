@@ -11,6 +11,7 @@
 // Memory-bound: reads and writes the logits matrix once.  No atomics: per-row losses go to [N, T] and are
 // summed by the caller in a fixed order.
 #include <cmath>
+#include <cstdlib>
 
 #include "agnn_common.h"
 
@@ -24,9 +25,8 @@ using agnn::row16_sum;
 // FOUR rows per wavefront; reductions are four DPP steps inside a 16-lane row (no cross-row traffic at all).
 // Segments up to 64 classes keep their logits in registers between the max / sum-exp / gradient passes (NK = 1..4
 // values per lane); wider ones re-read them (L1-resident).
-template <int NK>
-__device__ __forceinline__ void task_regs(const float* __restrict__ zr, float* __restrict__ dr, int a, int b, int sub, int64_t y, bool valid,
-                                          float sc, float eps, float& loss) {
+template <int NK, class PZ, class PD>
+__device__ __forceinline__ void task_regs(PZ zr, PD dr, int a, int b, int sub, int64_t y, bool valid, float sc, float eps, float& loss) {
   float v[NK];
   bool in[NK];
   float mx = -INFINITY;
@@ -57,15 +57,10 @@ __device__ __forceinline__ void task_regs(const float* __restrict__ zr, float* _
     if (in[k]) dr[a + sub + 16 * k] = sc * (e[k] * inv - ((yl == 16 * k ? 1.f - eps : 0.f) + sm));
 }
 
-__global__ __launch_bounds__(256) void k_mtce(const float* __restrict__ z, int64_t ld, const int32_t* __restrict__ off, int T,
-                                              const int64_t* __restrict__ labels, int64_t n_rows, float eps, int64_t ignore,
-                                              float* __restrict__ row_loss, float* __restrict__ dz) {
-  const int lane = threadIdx.x & 63, sub = lane & 15;
-  const int64_t row_raw = (static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
-  if (row_raw >= n_rows) return;                            // whole 16-lane rows drop out; DPP never crosses a row
-  const int64_t row = row_raw;
-  const float* zr = z + row * ld;
-  float* dr = dz + row * ld;
+// all tasks of one row (16 lanes): zr = the row's logits, dr = where its gradient goes (may be the same memory)
+template <class PZ, class PD>
+__device__ __forceinline__ void mtce_row(PZ zr, PD dr, const int32_t* __restrict__ off, int T, const int64_t* __restrict__ labels,
+                                         int64_t n_rows, int64_t row, int sub, float eps, int64_t ignore, float* __restrict__ row_loss) {
   for (int t = 0; t < T; ++t) {
     const int a = off[t], b = off[t + 1];
     const int C = b - a;
@@ -106,6 +101,61 @@ __global__ __launch_bounds__(256) void k_mtce(const float* __restrict__ z, int64
     }
     if (sub == 0) row_loss[static_cast<int64_t>(t) * n_rows + row] = bad ? NAN : loss;     // task-major: the reduction reads contiguously
   }
+}
+
+__global__ __launch_bounds__(256) void k_mtce(const float* __restrict__ z, int64_t ld, const int32_t* __restrict__ off, int T,
+                                              const int64_t* __restrict__ labels, int64_t n_rows, float eps, int64_t ignore,
+                                              float* __restrict__ row_loss, float* __restrict__ dz) {
+  const int lane = threadIdx.x & 63, sub = lane & 15;
+  const int64_t row = (static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+  if (row >= n_rows) return;                                // whole 16-lane rows drop out; DPP never crosses a row
+  mtce_row(z + row * ld, dz + row * ld, off, T, labels, n_rows, row, sub, eps, ignore, row_loss);
+}
+
+// The same through LDS: the 16 lanes of a row first fetch the WHOLE row (all loads in flight together, 64 contiguous bytes
+// per row and instruction), the task loop then reads and overwrites the LDS image (logits -> gradient in place), and the
+// gradient leaves as one pass of stores.  In k_mtce every task is its own global round trip — load, three 16-lane
+// reductions, store, 21 times in a row — and the kernel ran at 0.75 TB/s of traffic it touches exactly once (55 us at C2).
+// A row's 16 lanes only ever touch their own LDS row: no barrier, a wave-level fence between the phases.
+constexpr int kMtceMaxCols = 1024;      // LDS image: 4 waves x 4 rows x W floats (W = 634 at C2: 40 KB per workgroup)
+
+__global__ __launch_bounds__(256) void k_mtce_lds(const float* __restrict__ z, int64_t ld, const int32_t* __restrict__ off, int T,
+                                                  const int64_t* __restrict__ labels, int64_t n_rows, float eps, int64_t ignore,
+                                                  float* __restrict__ row_loss, float* __restrict__ dz) {
+  extern __shared__ float s_rows[];                         // [16 rows][ld]
+  const int lane = threadIdx.x & 63, sub = lane & 15;
+  const int slot = (threadIdx.x >> 6) * 4 + (lane >> 4);
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 16 + slot;
+  if (row >= n_rows) return;
+  const int lo = off[0], hi = off[T];                       // the columns the segments cover; anything else is left alone
+  float* sr = s_rows + static_cast<size_t>(slot) * ld;
+  const float* zr = z + row * ld;
+  float* dr = dz + row * ld;
+  for (int c0 = lo + sub; c0 < hi; c0 += 16 * 8) {          // eight loads in flight per lane and trip
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = c0 + 16 * k < hi ? zr[c0 + 16 * k] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (c0 + 16 * k < hi) sr[c0 + 16 * k] = v[k];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  mtce_row(sr, sr, off, T, labels, n_rows, row, sub, eps, ignore, row_loss);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int c = lo + sub; c < hi; c += 16) dr[c] = sr[c];
+}
+
+void launch_mtce(hipStream_t s, const float* logits, int64_t ld, const int32_t* seg_off, int n_tasks, const int64_t* labels, int64_t n_rows,
+                 float eps, int64_t ignore, float* row_loss, float* dlogits) {
+  const unsigned blocks = static_cast<unsigned>((n_rows + 15) / 16);   // 4 waves x 4 rows
+  static const bool plain = getenv("AGNN_MTCE_PLAIN") != nullptr;      // A/B switch (scripts)
+  if (ld > 0 && ld <= kMtceMaxCols && !plain)
+    hipLaunchKernelGGL(k_mtce_lds, dim3(blocks), dim3(256), static_cast<size_t>(16) * ld * sizeof(float), s, logits, ld, seg_off, n_tasks,
+                       labels, n_rows, eps, ignore, row_loss, dlogits);
+  else
+    hipLaunchKernelGGL(k_mtce, dim3(blocks), dim3(256), 0, s, logits, ld, seg_off, n_tasks, labels, n_rows, eps, ignore, row_loss, dlogits);
 }
 
 // loss[t] = sum_n row_loss[t][n] / max(count_t, 1),  inv_cnt[t] = 1 / max(count_t, 1),  count_t = #{n : labels[t][n] != ignore}.
@@ -356,10 +406,8 @@ extern "C" int agnn_multitask_ce_f32(const float* logits, int64_t ld, const int3
   if (n_rows == 0 || n_tasks == 0) return AGNN_OK;
   if (!logits || !seg_off || !labels || !row_loss || !dlogits || !loss || !inv_count) return fail(AGNN_EINVAL, "multitask_ce: null argument");
   if (label_smoothing < 0.f || label_smoothing >= 1.f) return fail(AGNN_EINVAL, "multitask_ce: label_smoothing=%f", label_smoothing);
-  const unsigned blocks = static_cast<unsigned>((n_rows + 15) / 16);   // 4 waves x 4 rows
   hipStream_t s = static_cast<hipStream_t>(stream_);
-  hipLaunchKernelGGL(k_mtce, dim3(blocks), dim3(256), 0, s, logits, ld, seg_off, n_tasks, labels, n_rows, label_smoothing,
-                     ignore_index, row_loss, dlogits);
+  launch_mtce(s, logits, ld, seg_off, n_tasks, labels, n_rows, label_smoothing, ignore_index, row_loss, dlogits);
   if (int rc = check_launch("multitask_ce")) return rc;
   hipLaunchKernelGGL(k_mtce_reduce, dim3(n_tasks), dim3(1024), 0, s, row_loss, labels, n_rows, ignore_index, loss, inv_count);
   return check_launch("multitask_ce_reduce");
@@ -390,9 +438,7 @@ extern "C" int agnn_train_loss_f32(const float* logits, int64_t ld, const int32_
   if (feat && (feat_cols <= 0 || ld_feat < feat_cols)) return fail(AGNN_EINVAL, "train_loss: feat_cols=%d ld_feat=%lld", feat_cols, (long long)ld_feat);
   if (workspace_bytes < agnn_train_loss_workspace_bytes() || (reinterpret_cast<uintptr_t>(workspace) & 255u)) return fail(AGNN_ENOMEM, "train_loss: workspace too small or not 256-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream_);
-  const unsigned blocks = static_cast<unsigned>((n_rows + 15) / 16);   // 4 waves x 4 rows
-  hipLaunchKernelGGL(k_mtce, dim3(blocks), dim3(256), 0, s, logits, ld, seg_off, n_tasks, labels, n_rows, label_smoothing,
-                     ignore_index, row_loss, dlogits);
+  launch_mtce(s, logits, ld, seg_off, n_tasks, labels, n_rows, label_smoothing, ignore_index, row_loss, dlogits);
   if (int rc = check_launch("train_loss/ce")) return rc;
   unsigned int* ticket = reinterpret_cast<unsigned int*>(workspace);
   float* fpart = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + 256);

@@ -338,7 +338,7 @@ extern "C" int agnn_norm_act_bwd_f32(const float* x, int64_t ld_x, const float* 
   using namespace agnn;
   if (seg <= 0 || seg > H) seg = H;
   if (int rc = na_check("norm_act_bwd", x, ld_x, gamma, beta, n, H, seg, p, rng_state)) return rc > 0 ? AGNN_OK : rc;
-  if (!dy || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace) return fail(AGNN_EINVAL, "norm_act_bwd: null argument");
+  if (!dy || !mean || !rstd || !dx || !workspace || (dgamma == nullptr) != (dbeta == nullptr)) return fail(AGNN_EINVAL, "norm_act_bwd: null argument");
   if (!aligned16(dy) || !aligned16(dx) || !aligned16(workspace) || (ld_dy & 3) || (ld_dx & 3)) return fail(AGNN_EALIGN, "norm_act_bwd: misaligned");
   if (workspace_bytes < agnn_norm_act_workspace_bytes(H)) return fail(AGNN_ENOMEM, "norm_act_bwd: workspace too small");
   NaArgs a{x, ld_x, gamma, beta, n, H, eps, p, flags, rng_state, call_id, seg};
@@ -349,7 +349,23 @@ extern "C" int agnn_norm_act_bwd_f32(const float* x, int64_t ld_x, const float* 
   const dim3 grid(nb), block(256);
   AGNN_NA_DISPATCH(k_na_bwd, a, dy, ld_dy, mean, rstd, dx, ld_dx, part);
   if (int rc = check_launch("norm_act_bwd")) return rc;
+  if (dgamma == nullptr) return AGNN_OK;              // the column sums are launched later: agnn_norm_act_colsum_f32
   const int width = 2 * H;
   hipLaunchKernelGGL(k_na_colsum, dim3((width + 31) / 32), dim3(1024), 0, s, part, nb, width, dgamma, dbeta, H);
+  return check_launch("norm_act_colsum");
+}
+
+extern "C" int agnn_norm_act_colsum_f32(const void* workspace, size_t workspace_bytes, int64_t n, int32_t H, float* dgamma, float* dbeta,
+                                        agnn_stream_t stream_) {
+  using namespace agnn;
+  if (n < 0 || H <= 0 || (H & 3) || H > 2048) return fail(AGNN_EINVAL, "norm_act_colsum: H=%d n=%lld", H, (long long)n);
+  if (n == 0) return AGNN_OK;
+  if (!workspace || !dgamma || !dbeta) return fail(AGNN_EINVAL, "norm_act_colsum: null argument");
+  if (workspace_bytes < agnn_norm_act_workspace_bytes(H)) return fail(AGNN_ENOMEM, "norm_act_colsum: workspace too small");
+  int nb = static_cast<int>((n + 3) / 4);                 // the partial rows agnn_norm_act_bwd_f32 wrote for n rows
+  if (nb > kBwdBlocks) nb = kBwdBlocks;
+  const int width = 2 * H;
+  hipLaunchKernelGGL(k_na_colsum, dim3((width + 31) / 32), dim3(1024), 0, static_cast<hipStream_t>(stream_),
+                     static_cast<const float*>(workspace), nb, width, dgamma, dbeta, H);
   return check_launch("norm_act_colsum");
 }

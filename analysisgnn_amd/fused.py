@@ -12,6 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
+from .linear import _steals, defer, deferring
 
 PRE_RELU, POST_RELU = 1, 2
 ENABLED = True
@@ -38,9 +39,13 @@ def _al16(t: torch.Tensor) -> torch.Tensor:
 
 class _NormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, p, flags, call_id, seg=0):
-        """x [n, H]; gamma / beta [H]; statistics over segments of `seg` floats (0 = the whole row)."""
+    def forward(ctx, x, gamma, beta, eps, p, flags, call_id, seg=0, defer_ok=False):
+        """x [n, H]; gamma / beta [H]; statistics over segments of `seg` floats (0 = the whole row).  `defer_ok`: gamma / beta
+        are leaves, or reach their leaves through views only (their gradients may be produced late: linear.defer_weight_grads)."""
         dev = _lib.require_gpu(x, gamma, beta)
+        ctx.defer_ok = bool(defer_ok) or (gamma.is_leaf and beta.is_leaf)
+        ctx.gamma_ref = gamma if gamma.is_leaf else None
+        ctx.beta_ref = beta if beta.is_leaf else None
         lib = _lib.load()
         x = x if (x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else x.contiguous()
         n, H = x.shape
@@ -74,11 +79,19 @@ class _NormAct(torch.autograd.Function):
         nws = int(lib.agnn_norm_act_workspace_bytes(H))
         ws = torch.empty(nws, dtype=torch.uint8, device=dev)
         rng = used[0] if p > 0 else None                     # the forward call's own (seed, step), not the live counter
+        # dgamma / dbeta only feed the optimizer: with deferred weight gradients (linear.defer_weight_grads) their column-sum
+        # launch leaves the chain too (the closure works on aliases: see linear._LinearFn.backward)
+        later = ctx.defer_ok and deferring(dy) and _steals(ctx.gamma_ref) and _steals(ctx.beta_ref)
         _lib.check(lib.agnn_norm_act_bwd_f32(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), seg, n, H, eps, p, flags,
                                              _lib.ptr(rng), call_id, dy.data_ptr(), dy.stride(0), mean.data_ptr(), rstd.data_ptr(),
-                                             dx.data_ptr(), dx.stride(0), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), nws,
-                                             _lib.stream_ptr(dev)), "agnn_norm_act_bwd_f32")
-        return dx, dgamma, dbeta, None, None, None, None, None
+                                             dx.data_ptr(), dx.stride(0), None if later else dgamma.data_ptr(),
+                                             None if later else dbeta.data_ptr(), ws.data_ptr(), nws, _lib.stream_ptr(dev)),
+                   "agnn_norm_act_bwd_f32")
+        if later:
+            dg_k, db_k = dgamma.detach(), dbeta.detach()
+            defer(lambda: _lib.check(lib.agnn_norm_act_colsum_f32(ws.data_ptr(), nws, n, H, dg_k.data_ptr(), db_k.data_ptr(),
+                                                                  _lib.stream_ptr(dev)), "agnn_norm_act_colsum_f32"), dev)
+        return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
 def norm_act(x: torch.Tensor, ln: nn.LayerNorm, pre_relu: bool = False, post_relu: bool = False, p: float = 0.0,
@@ -108,8 +121,9 @@ def grouped_norm_act(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, e
     if not ok:
         y = F.relu(x) if pre_relu else x
         return F.layer_norm(y, (H,), None, None, eps) * gamma + beta
+    view_only = all(t.is_leaf or getattr(t, "_agnn_wgrad_deferrable", False) for t in (gamma, beta))
     y = _NormAct.apply(x.reshape(N, W), gamma.reshape(W), beta.reshape(W), eps, 0.0, PRE_RELU if pre_relu else 0,
-                       next(_CALL_IDS) & 0xFFFFFFFF, H)
+                       next(_CALL_IDS) & 0xFFFFFFFF, H, view_only)
     return y.view(N, G, H)
 
 

@@ -35,8 +35,8 @@ def fused_head_logits(clf_dict: nn.ModuleDict, x: torch.Tensor, tasks: Sequence[
     W1 = mark_wgrad_async(cat_rows([m[0].weight for m in mods]), deferrable=True)          # [T*h2, o]; the cat's backward only takes views
     b1 = mark_wgrad_async(cat_rows([m[0].bias for m in mods]), deferrable=True)
     a = linear(x, W1, b1)                                                 # [N, T*h2]
-    gamma = stack_rows([m[2].weight for m in mods])                       # [T, h2]
-    beta = stack_rows([m[2].bias for m in mods])
+    gamma = mark_wgrad_async(stack_rows([m[2].weight for m in mods]), deferrable=True)      # [T, h2]; backward = views
+    beta = mark_wgrad_async(stack_rows([m[2].bias for m in mods]), deferrable=True)
     a = grouped_norm_act(a.view(-1, T, h2), gamma, beta, mods[0][2].eps, pre_relu=True)   # ReLU + per-task LayerNorm, one launch
     offs = [0]
     for m in mods:
@@ -228,8 +228,8 @@ def fused_logit_fusion(proj_layers: nn.ModuleDict, transformer: nn.Module, fusio
     Wp = torch.cat([m[0].weight.t() for m in pm], dim=0)                                 # [sum C, K]
     bp = cat_rows([m[0].bias for m in pm])                                                # [T*K]
     a = grouped_in_projection(logits, Wp, offs, K) + bp
-    gamma = stack_rows([m[2].weight for m in pm])
-    beta = stack_rows([m[2].bias for m in pm])
+    gamma = mark_wgrad_async(stack_rows([m[2].weight for m in pm]), deferrable=True)
+    beta = mark_wgrad_async(stack_rows([m[2].bias for m in pm]), deferrable=True)
     a = grouped_norm_act(a.view(N, T, K), gamma, beta, pm[0][2].eps, pre_relu=True)       # [N, T, K]
     enh = transformer(a)                                                                  # [N, T, K]
     Wf = cat_rows([fusion_layers[t].weight for t in tasks])                               # [sum C, K]

@@ -294,6 +294,12 @@ int agnn_norm_act_bwd_f32(const float* x, int64_t ld_x, const float* gamma, cons
                           int64_t ld_dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                           agnn_stream_t stream);
 
+/* agnn_norm_act_bwd_f32 with dgamma == dbeta == NULL leaves the per-block partial sums in `workspace` and launches only the
+ * input-gradient kernel; this entry point turns them into dgamma / dbeta later (same n, H, workspace): the two parameter
+ * gradients only feed the optimizer and need not sit on the backward pass's dependent chain. */
+int agnn_norm_act_colsum_f32(const void* workspace, size_t workspace_bytes, int64_t n, int32_t H, float* dgamma, float* dbeta,
+                             agnn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Weight-gradient GEMM of a projection layer y = x W^T + b over N rows (N large, out/in small):
  *     dw[out, in] = sum_n dy[n, out] * x[n, in]        db[out] = sum_n dy[n, out]   (db may be NULL)
