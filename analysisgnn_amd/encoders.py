@@ -35,7 +35,7 @@ from . import _lib, ops
 from .gru import gru_forward
 from .fused import FusedSequential, norm_act
 from .params import sage_operands, sage_operands_cat
-from .linear import Linear, deferring, flush_deferred, linear
+from .linear import Linear, deferring, flush_deferred, linear, set_home_stream
 from .core_layers import JumpingKnowledge
 from .graph import HeteroIndex, hetero_index
 
@@ -257,6 +257,14 @@ def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
     return _SIDE_STREAMS[idx]
 
 
+FLUSH_AT_JOIN = os.environ.get("AGNN_FLUSH_AT_JOIN", "0") == "1"     # A/B: issue the main stream's deferred work when the join is issued
+# The branch's deferred work is captured BEFORE the join's add: the add is then a later dependent of the branch's last kernel
+# and lands in the main stream's node list (with the tail behind it) instead of extending the branch's list — and the replay
+# starts feeding the main stream's list when the branch's list is nearly through (A/B: 3.40 vs 4.00 ms at C2).
+JOIN_AFTER_SIDE_FLUSH = os.environ.get("AGNN_JOIN_AFTER", "1") == "1"
+LATE_SEQUENCE_BACKWARD = os.environ.get("AGNN_SEQ_LATE", "1") == "1"  # A/B: the sequence branch behind a late-created node (_LateNode)
+
+
 class _FlushPoint(torch.autograd.Function):
     """Identity on the GNN stack's input.  Its backward runs where the stack's backward ends — where the main stream starts
     to idle until the sequence branch's backward arrives — and runs the weight gradients that the backward pass has deferred
@@ -268,7 +276,8 @@ class _FlushPoint(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        flush_deferred()
+        if not FLUSH_AT_JOIN:
+            flush_deferred()
         return g
 
 
@@ -288,15 +297,53 @@ class _ForkInput(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_gnn, g_seq):
+        if FLUSH_AT_JOIN:
+            flush_deferred(g_gnn.device if g_gnn is not None else None)
         g = g_gnn
+        if ctx.side is not None and JOIN_AFTER_SIDE_FLUSH:
+            with torch.cuda.stream(ctx.side):
+                flush_deferred(g.device if g is not None else None)
         if g_seq is not None:
             if g is None:
                 raise _lib.AgnnError("_ForkInput: the GNN stack produced no input gradient")   # both branches read the input
             g[:ctx.n] += g_seq                       # in place: the GNN stack's gradient is this node's alone
-        if ctx.side is not None:
+        if ctx.side is not None and not JOIN_AFTER_SIDE_FLUSH:
             with torch.cuda.stream(ctx.side):
                 flush_deferred(g.device if g is not None else None)
         return g, None, None
+
+
+class _Inner:
+    """The sequence branch's own autograd graph: its output and the detached leaf it was built on."""
+
+    def __init__(self, z, x_leaf):
+        self.z, self.x_leaf = z, x_leaf
+
+
+class _LateNode(torch.autograd.Function):
+    """Stands for the sequence branch in the outer autograd graph (deferred weight gradients only).  The branch's kernels are
+    issued FIRST in the forward pass, but the autograd engine runs ready nodes NEWEST first: a branch recorded first is
+    differentiated — and captured — after the whole GNN stack, and a replayed hipGraph feeds its per-stream node lists to
+    the GPU one after the other, the next list once the previous one is down to its last ~12 nodes
+    (scripts/graph_window_probe.py): the recurrence's backward, the step's longest chain, then starts ~0.5 ms after its
+    input gradient exists.  So the branch is recorded on a detached leaf and this node — created after the GNN stack, hence
+    the newest — differentiates it with a nested backward pass: its chain is captured first, and with every piece of
+    optimizer-only work deferred it is 9 kernels long, so the GNN stack's list is fed right behind it."""
+
+    @staticmethod
+    def forward(ctx, x_seq, inner: _Inner):
+        ctx.inner = inner
+        return inner.z.detach()
+
+    @staticmethod
+    def backward(ctx, dz):
+        inner, ctx.inner = ctx.inner, None
+        if dz is None:
+            return None, None
+        torch.autograd.backward([inner.z], [dz])
+        g = inner.x_leaf.grad if inner.x_leaf.requires_grad else None
+        inner.x_leaf.grad = None
+        return g, None
 
 
 class _HybridMixin:
@@ -352,6 +399,15 @@ class _HybridMixin:
             self._gnn_note = _FlushPoint.apply(x_gnn)
         side.wait_stream(main)
 
+        set_home_stream(main)
+        if x_seq is not None and LATE_SEQUENCE_BACKWARD:
+            with torch.cuda.stream(side):
+                x_leaf = x_seq.detach().requires_grad_(True)
+                inner = self.hybrid_forward(x_leaf, batch_note)
+            if inner.requires_grad:
+                return (x_seq, _Inner(inner, x_leaf)), side        # the node is created in `_finish`, after the GNN stack
+            return inner, side
+
         def branch():
             with torch.cuda.stream(side):
                 return self.hybrid_forward(x_seq if x_seq is not None else _head(x_in, batch_size), batch_note)
@@ -370,6 +426,9 @@ class _HybridMixin:
             x = self.jk([_head(o, batch_size) for o in outs])
         if callable(z):
             z = z()
+        if isinstance(z, tuple):
+            with torch.cuda.stream(side):                # the node belongs to the side stream, like the branch it stands for
+                z = _LateNode.apply(*z)
         if side is not None:
             torch.cuda.current_stream(x.device).wait_stream(side)
             z.record_stream(torch.cuda.current_stream(x.device))
