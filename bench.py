@@ -69,6 +69,8 @@ def parse_args(argv=None):
     ap.add_argument("--mt-strategy", default="wloss", choices=["wloss", "sum"],
                     help="wloss (reference CLI default): learned uncertainty weights per task; sum: plain sum of the task losses")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying hipGraphs")
+    ap.add_argument("--schedule", default="auto", choices=["auto", "late", "plain"],
+                    help="backward schedule of the hybrid encoders: capture both and keep the faster (auto), or force one")
     ap.add_argument("--no-defer", action="store_true", help="A/B only: weight gradients where they are computed, not deferred")
     ap.add_argument("--no-wgrad-overlap", action="store_true", help="A/B only: weight gradients on the main stream")
     ap.add_argument("--library-wgrad", action="store_true", help="A/B only: weight gradients through the library GEMM")
@@ -301,12 +303,38 @@ def main():
                     fwd_bwd(); flat.all_reduce_mean(); update()
             torch.cuda.current_stream(dev).wait_stream(side)
             dp.barrier_and_sync()                               # no collective in flight on any rank while capturing
-            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            g2 = torch.cuda.CUDAGraph()
             dot = os.environ.get("AGNN_GRAPH_DOT")               # the captured step's dependency graph as DOT (debugging)
-            with torch.cuda.graph(g1):
-                loss_ref[0] = fwd_bwd()
-                if dot:
-                    _dump_capture_dot(dot, dev)
+            # Which of the two backward schedules of the hybrid encoders replays faster depends on how many nodes each
+            # branch of the captured graph has (profiles/r02_step_timeline.md: c2s 3.39 vs 3.45 ms, c2 3.61 vs 3.54 ms), so
+            # both are captured and the faster one (6 replays each, slowest rank decides) is kept — TunableOp's way.
+            from analysisgnn_amd import encoders as _enc
+            tune = args.schedule == "auto" and enc in ("hybridgnn", "hgt") and not args.no_defer and not dot
+            variants = [True, False] if tune else [{"late": True, "plain": False, "auto": _enc.LATE_SEQUENCE_BACKWARD}[args.schedule]]
+            best = None
+            for late in variants:
+                _enc.LATE_SEQUENCE_BACKWARD = late
+                g1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    loss_v = fwd_bwd()
+                    if dot:
+                        _dump_capture_dot(dot, dev)
+                t_v = 0.0
+                if len(variants) > 1:
+                    g1.replay()
+                    dp.barrier_and_sync()
+                    t0 = time.perf_counter()
+                    for _ in range(6):
+                        g1.replay()
+                    dp.barrier_and_sync()
+                    t_v = dp.max_over_ranks(time.perf_counter() - t0)
+                if best is None or t_v < best[0]:
+                    best = (t_v, g1, loss_v, late)
+            _, g1, loss_ref[0], schedule_late = best
+            _enc.LATE_SEQUENCE_BACKWARD = schedule_late
+            if rank == 0 and len(variants) > 1:
+                print(f"[bench] backward schedule: sequence branch {'behind a late node' if schedule_late else 'in autograd order'}",
+                      file=sys.stderr)
             with torch.cuda.graph(g2):
                 update()
             graphs = (g1, g2)
