@@ -75,6 +75,54 @@ def test_graph_replay_equals_eager_step_and_is_reproducible(defer):
         graph.index_cache_enabled = was
 
 
+@pytest.mark.parametrize("late", [True, False])
+def test_deferred_weight_gradients_on_ragged_sampled_batch(late):
+    """dp.defer_weight_grads with both backward schedules of the hybrid encoder (the sequence branch behind a late-created node
+    / in autograd order) on a neighbour-sampled batch whose three subgraphs have DIFFERENT lengths (padded sequences, every
+    layer trimmed, the last one without edges): loss and every gradient bit-identical to the plain step."""
+    from analysisgnn_amd import dp, encoders, graph
+    from analysisgnn_amd.heads import MultiTaskLoss, training_loss
+    from analysisgnn_amd.models import TorchAnalysisGNN
+    from analysisgnn_amd.synth import make_score_graph, merge_sampled, sample_hops, torch_inputs
+    dev = torch.device("cuda", 0)
+    tasks = {"cadence": 4, "localkey": 50, "hrythm": 2}
+    g = merge_sampled([sample_hops(make_score_graph(seed=sd, n_notes=400), nt, (5, 5), seed=sd, first_target=20)
+                       for sd, nt in ((1, 150), (2, 90), (3, 201))])
+    I = torch_inputs(g, 25, dev, seed=0)
+    labels = torch.stack([torch.randint(0, c, (I["batch_size"],), generator=torch.Generator().manual_seed(i)).to(dev)
+                          for i, c in enumerate(tasks.values())])
+    torch.manual_seed(0)
+    model = TorchAnalysisGNN(g.metadata(), 25, 256, 128, tasks, 3, dropout=0.0, use_jk=False, logit_fusion=False).to(dev).train()
+    clf = MultiTaskLoss(list(tasks)).to(dev)
+    both = torch.nn.ModuleDict({"m": model, "c": clf})
+    flat = dp.FlatGradBuffer(both.parameters(), views=False)
+    was, was_late = graph.index_cache_enabled, encoders.LATE_SEQUENCE_BACKWARD
+    graph.index_cache_enabled = False
+    dp.enable_wgrad_overlap(True, "sequence")
+
+    def fwd_bwd():
+        flat.zero()
+        x = model.encode(I["pitch_spelling"], I["key_signature"], I["x_dict"], I["edge_index_dict"], I["batch_dict"], I["batch_size"],
+                         I["neighbor_mask_node"], I["neighbor_mask_edge"])
+        logits, offs, _ = model.forward_clf_fused(x)
+        loss, _ = training_loss(logits, offs, labels, x, 0.1, 0.1, -1, task_params=clf.weights())
+        loss.backward()
+        flat.pack()
+        return float(loss), flat.flat.clone()
+    try:
+        l0, g0 = fwd_bwd()
+        assert torch.isfinite(g0).all() and float(g0.abs().max()) > 0
+        encoders.LATE_SEQUENCE_BACKWARD = late
+        dp.defer_weight_grads(True)
+        l1, g1 = fwd_bwd()
+        assert l1 == l0 and torch.equal(g1, g0), float((g1 - g0).abs().max())
+    finally:
+        dp.defer_weight_grads(False)
+        dp.enable_wgrad_overlap(False)
+        encoders.LATE_SEQUENCE_BACKWARD = was_late
+        graph.index_cache_enabled = was
+
+
 def test_adjacent_parameter_layout_gives_the_same_step():
     """dp.plan_parameters + FlatAdamW put the task-head layers and the GRU direction pairs back to back, so the fused
     schedule reads them through views (params.cat_rows / stack_rows) instead of cat / pack launches: same loss and the same
