@@ -245,9 +245,6 @@ def _head(t: torch.Tensor, n: int) -> torch.Tensor:
 
 
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
-# A/B switch: issue the sequence branch AFTER the GNN stack (it still forks where the input is ready).  The autograd engine
-# runs ready nodes newest-first, so the branch issued last in the forward pass is differentiated — and captured — first.
-SEQUENCE_BRANCH_LAST = os.environ.get("AGNN_SEQ_LAST", "0") == "1"
 
 
 def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
@@ -257,11 +254,6 @@ def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
     return _SIDE_STREAMS[idx]
 
 
-FLUSH_AT_JOIN = os.environ.get("AGNN_FLUSH_AT_JOIN", "0") == "1"     # A/B: issue the main stream's deferred work when the join is issued
-# The branch's deferred work is captured BEFORE the join's add: the add is then a later dependent of the branch's last kernel
-# and lands in the main stream's node list (with the tail behind it) instead of extending the branch's list — and the replay
-# starts feeding the main stream's list when the branch's list is nearly through (A/B: 3.40 vs 4.00 ms at C2).
-JOIN_AFTER_SIDE_FLUSH = os.environ.get("AGNN_JOIN_AFTER", "1") == "1"
 LATE_SEQUENCE_BACKWARD = os.environ.get("AGNN_SEQ_LATE", "1") == "1"  # A/B: the sequence branch behind a late-created node (_LateNode)
 
 
@@ -276,8 +268,7 @@ class _FlushPoint(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        if not FLUSH_AT_JOIN:
-            flush_deferred()
+        flush_deferred()
         return g
 
 
@@ -286,8 +277,8 @@ class _ForkInput(torch.autograd.Function):
     join of the two backward passes: the sequence branch's input gradient is added onto the first n rows of the GNN stack's
     (one launch over n rows, on the main stream), instead of autograd's SliceBackward (a full-size zero fill and a copy, on
     the branch's stream — as late dependents of the recurrence's last GEMM they started ~0.18 ms after it in the replayed
-    graph) plus a full-size gradient add.  Only then — captured after the join, so that the join is the first dependent of
-    that GEMM — the sequence branch's deferred weight gradients are issued on its own stream."""
+    graph) plus a full-size gradient add.  The sequence branch's deferred weight gradients are issued here as well, on the
+    branch's stream, BEFORE the add is captured (see backward)."""
 
     @staticmethod
     def forward(ctx, x, n, side):
@@ -297,19 +288,17 @@ class _ForkInput(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_gnn, g_seq):
-        if FLUSH_AT_JOIN:
-            flush_deferred(g_gnn.device if g_gnn is not None else None)
         g = g_gnn
-        if ctx.side is not None and JOIN_AFTER_SIDE_FLUSH:
+        # The branch's deferred work is captured BEFORE the join's add: the add is then a later dependent of the branch's last
+        # kernel and lands in the main stream's node list (with the tail behind it) instead of extending the branch's list —
+        # and the replay starts feeding the main stream's list when the branch's list is nearly through (3.40 vs 4.00 ms).
+        if ctx.side is not None:
             with torch.cuda.stream(ctx.side):
                 flush_deferred(g.device if g is not None else None)
         if g_seq is not None:
             if g is None:
                 raise _lib.AgnnError("_ForkInput: the GNN stack produced no input gradient")   # both branches read the input
             g[:ctx.n] += g_seq                       # in place: the GNN stack's gradient is this node's alone
-        if ctx.side is not None and not JOIN_AFTER_SIDE_FLUSH:
-            with torch.cuda.stream(ctx.side):
-                flush_deferred(g.device if g is not None else None)
         return g, None, None
 
 
@@ -407,13 +396,9 @@ class _HybridMixin:
             if inner.requires_grad:
                 return (x_seq, _Inner(inner, x_leaf)), side        # the node is created in `_finish`, after the GNN stack
             return inner, side
-
-        def branch():
-            with torch.cuda.stream(side):
-                return self.hybrid_forward(x_seq if x_seq is not None else _head(x_in, batch_size), batch_note)
-        if SEQUENCE_BRANCH_LAST:
-            return branch, side                      # issued by `_finish`, behind the GNN stack (A/B switch, see there)
-        return branch(), side
+        with torch.cuda.stream(side):
+            z = self.hybrid_forward(x_seq if x_seq is not None else _head(x_in, batch_size), batch_note)
+        return z, side
 
     def _gnn_input(self, x_dict, side):
         """The GNN stack's input: the dict itself, or (deferred weight gradients) the note matrix behind the flush point."""
@@ -424,8 +409,6 @@ class _HybridMixin:
         x = _head(x_note, batch_size)
         if self.use_jk:
             x = self.jk([_head(o, batch_size) for o in outs])
-        if callable(z):
-            z = z()
         if isinstance(z, tuple):
             with torch.cuda.stream(side):                # the node belongs to the side stream, like the branch it stands for
                 z = _LateNode.apply(*z)

@@ -14,7 +14,6 @@ from . import _lib
 from .linear import defer, defer_home, deferring, mark_wgrad_async, weight_grad, wgrad_stream
 
 KERNEL_HIDDEN = 128
-_L1_FORK = __import__("os").environ.get("AGNN_L1_FORK", "0") == "1"     # A/B: fork the inner layers' weight gradients as before
 
 
 class _GRULayer(torch.autograd.Function):
@@ -84,8 +83,8 @@ class _GRULayer(torch.autograd.Function):
         # Any other layer, with deferred weight gradients on a branch stream: no fork either (a fork inside the chain makes the
         # chain's own continuation a later-captured dependent) — the work goes to the main chain's flush, behind an event.
         if ctx.last_in_backward and ctx.wg_async and deferring(dy):
-            defer(forked, dev, local=True)
-        elif _L1_FORK or not (ctx.wg_async and deferring(dy) and defer_home(weight_grads, dev)):
+            defer(forked, dev)
+        elif not (ctx.wg_async and deferring(dy) and defer_home(weight_grads, dev)):
             forked()
         return dx, dw_ih.view(2, 3 * Hh, I), dw_hh, db_ih.view(2, 3 * Hh), db_hh, None
 

@@ -107,7 +107,6 @@ class wgrad_stream:
 # Only for gradients that autograd takes over without a kernel (`_steals`).  Closures are kept per stream and run on the
 # stream that deferred them (their operands were produced there).
 # ------------------------------------------------------------------------------------------------------------
-_ROUTE_HOME = __import__("os").environ.get("AGNN_ROUTE_HOME", "0") == "1"      # A/B switch (measured slower: 3.46 vs 3.39 ms at C2)
 _DEFER = {"on": False, "pending": {}}        # pending: (device index, stream handle) -> (stream, [closures])
 
 
@@ -121,11 +120,10 @@ def deferring(t: torch.Tensor) -> bool:
     return bool(_DEFER["on"] and t.is_cuda)
 
 
-def defer(fn, dev, local: bool = False) -> None:
-    """Queue optimizer-only work.  From a branch stream it goes to the main chain's flush (behind an event recorded now:
-    `defer_home`) unless `local`: then it stays with the stream that deferred it and runs at that stream's own flush."""
-    if not local and _ROUTE_HOME and defer_home(fn, dev):
-        return
+def defer(fn, dev) -> None:
+    """Queue optimizer-only work on the CURRENT stream's list: it runs at that stream's flush.  (Sending a branch stream's
+    projections to the main chain's flush instead — `defer_home` — measured slower, 3.46 vs 3.39 ms at C2; only the inner
+    recurrent layers' weight gradients go that way, because they must run beside the next layer's recurrence.)"""
     s = torch.cuda.current_stream(dev)
     _DEFER["pending"].setdefault((s.device.index, s.cuda_stream), (s, []))[1].append(fn)
 
