@@ -80,7 +80,9 @@ class wgrad_stream:
         ws = _WG["streams"].get(idx)
         if ws is None:
             ws = _WG["streams"][idx] = torch.cuda.Stream(device=self.dev)
-        ws.wait_stream(torch.cuda.current_stream(self.dev))
+        cur = torch.cuda.current_stream(self.dev)
+        if cur.cuda_stream != ws.cuda_stream:           # already on it (nested use): a stream must not wait for itself in a capture
+            ws.wait_stream(cur)
         self.ws = ws
         self.ctx = torch.cuda.stream(ws)
         self.ctx.__enter__()
