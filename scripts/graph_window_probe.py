@@ -3,7 +3,7 @@
 main stream: A, then m1..mK (short element-wise kernels, ~16 us); side stream (forks after A): one LONG spin kernel L
 (torch.cuda._sleep), then s1..s3.  The side chain is captured before the m's (`first`), after them (`last`) or after the
 first P of them (`mid`).  rocprofv3 --kernel-trace + graph_window_probe_report.py give when L and each m start.
-usage: graph_window_probe.py first|last|mid [K] [P]"""
+usage: graph_window_probe.py first|last|mid [K] [P] [J]"""
 import sys
 
 import torch
@@ -11,6 +11,7 @@ import torch
 where = sys.argv[1]
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 P = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+J = int(sys.argv[4]) if len(sys.argv) > 4 else 3         # short kernels behind the long one on the side chain
 dev = torch.device("cuda:0")
 a = torch.randn(2048, 2048, device=dev)
 b = torch.randn(2048, 2048, device=dev)
@@ -25,7 +26,7 @@ def side_chain(ev):
     side.wait_event(ev)
     with torch.cuda.stream(side):
         torch.cuda._sleep(SPIN)
-        for _ in range(3):
+        for _ in range(J):
             xs.cos_()
 
 
