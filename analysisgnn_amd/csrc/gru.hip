@@ -49,9 +49,15 @@ __device__ __forceinline__ float tanhf_(float x) { return 2.f * __builtin_amdgcn
 // Tried, slower: two EXTRA waves for phase 2 (640 threads) with their stores deferred behind the second barrier.
 constexpr int PSTR = 3 * HH;           // part[kc][gate*HH + unit]
 
+// Inter-layer dropout rides along (nn.GRU(dropout=p), models/cadence.py:249-251): `drop` [B, T, 2*HH] holds 0 or 1 / (1 - p)
+// per element and `y2` receives y * drop — what the next layer reads — while `y` stays the layer's own state; without
+// dropout the host passes drop = any readable matrix of that size, use = 0 and y2 = y (the loads / stores stay
+// unconditional: a branch around a memory operation costs a full wait in this loop).  One launch less on the recurrence
+// chain in each direction (the backward kernel applies the same factor to dy).
 __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, const float* __restrict__ w_hh,
                                                  const float* __restrict__ b_hh, int T, float* __restrict__ y,
-                                                 float* __restrict__ saved) {
+                                                 float* __restrict__ saved, const float* __restrict__ drop, float use,
+                                                 float* __restrict__ y2) {
   __shared__ __attribute__((aligned(16))) float hbuf[2][HH];
   __shared__ __attribute__((aligned(16))) float part[KC * PSTR];
   const int b = blockIdx.x >> 1, d = blockIdx.x & 1;
@@ -105,15 +111,16 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
   const float bh0 = b_hh[d * 3 * HH + u], bh1 = b_hh[d * 3 * HH + HH + u], bh2 = b_hh[d * 3 * HH + 2 * HH + u];
   float hprev = 0.f;
   const size_t row3 = static_cast<size_t>(2) * 3 * HH;
-  auto load_gi = [&](int s_, float (&g3)[3]) {
+  auto load_gi = [&](int s_, float (&g3)[4]) {
     const int sc = s_ < T ? s_ : T - 1;
     const int t_ = d ? T - 1 - sc : sc;
     const float* p = gi + (static_cast<size_t>(b) * T + t_) * row3 + static_cast<size_t>(d) * 3 * HH + u;
     g3[0] = p[0];
     g3[1] = p[HH];
     g3[2] = p[2 * HH];
+    g3[3] = drop[(static_cast<size_t>(b) * T + t_) * 2 * HH + d * HH + u];
   };
-  auto phase2 = [&](int s, float (&gin)[3]) {
+  auto phase2 = [&](int s, float (&gin)[4]) {
     const int cur = s & 1;
     const int t = d ? T - 1 - s : s;
     float p0[KC], p1[KC], p2[KC];
@@ -135,6 +142,7 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
     hbuf[cur ^ 1][u] = hnew;
     const size_t bt = static_cast<size_t>(b) * T + t;
     y[bt * 2 * HH + d * HH + u] = hnew;
+    y2[bt * 2 * HH + d * HH + u] = hnew * fmaf(use, gin[3] - 1.f, 1.f);
     float* sv = saved + (bt * 2 + d) * 4 * HH + u;
     sv[0] = rr;
     sv[HH] = zz;
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
     sv[3 * HH] = s2;
     load_gi(s + 4, gin);                 // refill this ring slot
   };
-  float g0[3], g1[3], g2[3], g3[3];
+  float g0[4], g1[4], g2[4], g3[4];
   load_gi(0, g0);
   load_gi(1, g1);
   load_gi(2, g2);
@@ -169,7 +177,8 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
 //            address for all lanes), 48 packed FMAs, two partial sums to LDS.
 __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, const float* __restrict__ y,
                                                  const float* __restrict__ saved, const float* __restrict__ w_hh,
-                                                 int T, float* __restrict__ dgi, float* __restrict__ dgh_out) {
+                                                 int T, float* __restrict__ dgi, float* __restrict__ dgh_out,
+                                                 const float* __restrict__ drop, float use) {
   __shared__ __attribute__((aligned(16))) float dgh[3 * HH];
   __shared__ __attribute__((aligned(16))) float cpart[KC * HH];
   constexpr int CSTR = HH;
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, co
     const int t_ = d ? sc : T - 1 - sc;          // reverse of the forward walk
     const int tp_ = d ? t_ + 1 : t_ - 1;
     const size_t bt_ = static_cast<size_t>(b) * T + t_;
-    o.dyv = dy[bt_ * 2 * HH + d * HH + u];
+    o.dyv = dy[bt_ * 2 * HH + d * HH + u] * fmaf(use, drop[bt_ * 2 * HH + d * HH + u] - 1.f, 1.f);   // dy is d(y * drop)
     const float* sv = saved + (bt_ * 2 + d) * 4 * HH + u;
     o.r = sv[0];
     o.z = sv[HH];
@@ -306,20 +315,24 @@ extern "C" int agnn_gru_hprev_f32(const float* y, int64_t B, int64_t T, int32_t 
 }
 
 extern "C" int agnn_gru_fwd_f32(const float* gi, const float* w_hh, const float* b_hh, int64_t B, int64_t T,
-                                int32_t hidden, float* y, float* saved, agnn_stream_t stream_) {
+                                int32_t hidden, float* y, float* saved, const float* drop_scale, float* y_drop,
+                                agnn_stream_t stream_) {
   using namespace agnn;
   if (hidden != HH) return fail(AGNN_EINVAL, "gru_fwd: hidden=%d unsupported (this build: %d)", hidden, HH);
   if (B < 0 || T < 0 || B * 2 >= (int64_t{1} << 31) || T >= (int64_t{1} << 31)) return fail(AGNN_EINVAL, "gru_fwd: bad B=%lld T=%lld", (long long)B, (long long)T);
   if (B == 0 || T == 0) return AGNN_OK;
   if (!gi || !w_hh || !b_hh || !y || !saved) return fail(AGNN_EINVAL, "gru_fwd: null argument");
   if (!aligned16(gi) || !aligned16(w_hh) || !aligned16(y) || !aligned16(saved)) return fail(AGNN_EALIGN, "gru_fwd: pointers must be 16-byte aligned");
+  if ((drop_scale == nullptr) != (y_drop == nullptr)) return fail(AGNN_EINVAL, "gru_fwd: drop_scale and y_drop go together");
   hipLaunchKernelGGL(k_gru_fwd, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), gi,
-                       w_hh, b_hh, static_cast<int>(T), y, saved);
+                       w_hh, b_hh, static_cast<int>(T), y, saved, drop_scale ? drop_scale : y, drop_scale ? 1.f : 0.f,
+                       y_drop ? y_drop : y);
   return check_launch("gru_fwd");
 }
 
 extern "C" int agnn_gru_bwd_f32(const float* dy, const float* y, const float* saved, const float* w_hh, int64_t B,
-                                int64_t T, int32_t hidden, float* dgi, float* dgh, agnn_stream_t stream_) {
+                                int64_t T, int32_t hidden, float* dgi, float* dgh, const float* drop_scale,
+                                agnn_stream_t stream_) {
   using namespace agnn;
   if (hidden != HH) return fail(AGNN_EINVAL, "gru_bwd: hidden=%d unsupported (this build: %d)", hidden, HH);
   if (B < 0 || T < 0 || B * 2 >= (int64_t{1} << 31) || T >= (int64_t{1} << 31)) return fail(AGNN_EINVAL, "gru_bwd: bad B=%lld T=%lld", (long long)B, (long long)T);
@@ -327,6 +340,6 @@ extern "C" int agnn_gru_bwd_f32(const float* dy, const float* y, const float* sa
   if (!dy || !y || !saved || !w_hh || !dgi || !dgh) return fail(AGNN_EINVAL, "gru_bwd: null argument");
   if (!aligned16(dy) || !aligned16(y) || !aligned16(saved) || !aligned16(w_hh) || !aligned16(dgi) || !aligned16(dgh)) return fail(AGNN_EALIGN, "gru_bwd: pointers must be 16-byte aligned");
   hipLaunchKernelGGL(k_gru_bwd, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), dy, y,
-                       saved, w_hh, static_cast<int>(T), dgi, dgh);
+                       saved, w_hh, static_cast<int>(T), dgi, dgh, drop_scale ? drop_scale : y, drop_scale ? 1.f : 0.f);
   return check_launch("gru_bwd");
 }

@@ -18,7 +18,10 @@ KERNEL_HIDDEN = 128
 
 class _GRULayer(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, last_in_backward=False):
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, last_in_backward=False, drop_scale=None):
+        """`drop_scale` [B, T, 2*H] (0 or 1 / (1 - p) per element): the layer's OUTPUT is y * drop_scale — nn.GRU's inter-layer
+        dropout — written by the recurrence kernel itself; the backward kernel applies the same factor to the incoming
+        gradient.  (As separate launches the dropout and its backward sat on the recurrence chain in both directions.)"""
         ctx.last_in_backward = bool(last_in_backward)
         # x [B,T,I]; w_ih [2,3H,I]; w_hh [2,3H,H]; b_ih, b_hh [2,3H]
         dev = _lib.require_gpu(x, w_ih, w_hh, b_ih, b_hh)
@@ -32,16 +35,23 @@ class _GRULayer(torch.autograd.Function):
         y = torch.empty((B, T, 2 * Hh), dtype=torch.float32, device=dev)
         saved = torch.empty((B, T, 2, 4, Hh), dtype=torch.float32, device=dev)
         lib = _lib.load()
+        out = y
+        if drop_scale is not None:
+            if tuple(drop_scale.shape) != (B, T, 2 * Hh) or drop_scale.dtype != torch.float32 or not drop_scale.is_contiguous():
+                raise _lib.AgnnError("gru: drop_scale must be a contiguous fp32 [B, T, 2*hidden] tensor")
+            out = torch.empty_like(y)
         _lib.check(lib.agnn_gru_fwd_f32(gi.data_ptr(), w_hh_c.data_ptr(), b_hh_c.data_ptr(), B, T, Hh,
-                                        y.data_ptr(), saved.data_ptr(), _lib.stream_ptr(dev)), "agnn_gru_fwd_f32")
-        ctx.save_for_backward(x2, w_ih, w_hh_c, y, saved)
+                                        y.data_ptr(), saved.data_ptr(), _lib.ptr(drop_scale), out.data_ptr() if drop_scale is not None else None,
+                                        _lib.stream_ptr(dev)), "agnn_gru_fwd_f32")
+        ctx.save_for_backward(x2, w_ih, w_hh_c, y, saved, *([drop_scale] if drop_scale is not None else []))
         ctx.dims = (B, T, I, Hh)
         ctx.wg_async = all(getattr(t, "_agnn_wgrad_async", False) or t.is_leaf for t in (w_ih, w_hh, b_ih, b_hh))
-        return y
+        return out
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w_ih, w_hh, y, saved = ctx.saved_tensors
+        x2, w_ih, w_hh, y, saved, *drop = ctx.saved_tensors
+        drop_scale = drop[0] if drop else None
         B, T, I, Hh = ctx.dims
         dev = dy.device
         dy = dy.contiguous()
@@ -49,7 +59,7 @@ class _GRULayer(torch.autograd.Function):
         dgh = torch.empty((B, T, 2, 3 * Hh), dtype=torch.float32, device=dev)      # (d r_pre, d z_pre, d n_pre * r)
         lib = _lib.load()
         _lib.check(lib.agnn_gru_bwd_f32(dy.data_ptr(), y.data_ptr(), saved.data_ptr(), w_hh.data_ptr(), B, T, Hh,
-                                        dgi.data_ptr(), dgh.data_ptr(), _lib.stream_ptr(dev)), "agnn_gru_bwd_f32")
+                                        dgi.data_ptr(), dgh.data_ptr(), _lib.ptr(drop_scale), _lib.stream_ptr(dev)), "agnn_gru_bwd_f32")
         dgi2 = dgi.view(B * T, 6 * Hh)
         wf = w_ih.reshape(6 * Hh, I)
         dx = (dgi2 @ wf).view(B, T, I) if ctx.needs_input_grad[0] else None
@@ -86,7 +96,7 @@ class _GRULayer(torch.autograd.Function):
             defer(forked, dev)
         elif not (ctx.wg_async and deferring(dy) and defer_home(weight_grads, dev)):
             forked()
-        return dx, dw_ih.view(2, 3 * Hh, I), dw_hh, db_ih.view(2, 3 * Hh), db_hh, None
+        return dx, dw_ih.view(2, 3 * Hh, I), dw_hh, db_ih.view(2, 3 * Hh), db_hh, None, None
 
 
 def kernel_applicable(rnn: nn.GRU) -> bool:
@@ -104,10 +114,25 @@ def gru_forward(rnn: nn.GRU, x: torch.Tensor, training: bool) -> torch.Tensor:
     stacked = _stack_gru_params(rnn)
     for layer in range(rnn.num_layers):
         w_ih, w_hh, b_ih, b_hh = stacked[4 * layer:4 * layer + 4]
-        y = _GRULayer.apply(y.contiguous(), w_ih, w_hh, b_ih, b_hh, layer == 0)
+        drop = None
         if layer < rnn.num_layers - 1 and rnn.dropout > 0 and training:
-            y = F.dropout(y, rnn.dropout, True)
+            B, T = y.shape[0], y.shape[1]
+            drop = F.dropout(_ones((B, T, 2 * rnn.hidden_size), y.device), rnn.dropout, True)     # 0 or 1 / (1 - p): one launch
+        y = _GRULayer.apply(y.contiguous(), w_ih, w_hh, b_ih, b_hh, layer == 0, drop)
     return y
+
+
+_ONES: dict = {}
+
+
+def _ones(shape, device) -> torch.Tensor:
+    key = (tuple(shape), str(device))
+    t = _ONES.get(key)
+    if t is None:
+        if len(_ONES) >= 8:
+            _ONES.pop(next(iter(_ONES)))
+        t = _ONES[key] = torch.ones(shape, dtype=torch.float32, device=device)
+    return t
 
 
 class _StackPairs(torch.autograd.Function):

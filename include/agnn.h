@@ -191,10 +191,14 @@ int agnn_spmm_self_grad_f32(const float* dout, int64_t ld_dout, int64_t rel_stri
  * weight/input gradients are GEMMs over those.
  * ------------------------------------------------------------------------------------------ */
 int agnn_gru_fwd_f32(const float* gi, const float* w_hh, const float* b_hh, int64_t B, int64_t T,
-                     int32_t hidden, float* y, float* saved, agnn_stream_t stream);
-int agnn_gru_bwd_f32(const float* dy, const float* y, const float* saved, const float* w_hh,
-                     int64_t B, int64_t T, int32_t hidden, float* dgi, float* dgh,
+                     int32_t hidden, float* y, float* saved, const float* drop_scale, float* y_drop,
                      agnn_stream_t stream);
+int agnn_gru_bwd_f32(const float* dy, const float* y, const float* saved, const float* w_hh,
+                     int64_t B, int64_t T, int32_t hidden, float* dgi, float* dgh, const float* drop_scale,
+                     agnn_stream_t stream);
+/* Inter-layer dropout of `nn.GRU(dropout=p)` (ref: models/cadence.py:249-251) rides along: drop_scale [B, T, 2*hidden]
+ * holds 0 or 1 / (1 - p) per element; forward additionally writes y_drop = y * drop_scale (the next layer's input),
+ * backward takes dy = d(y_drop) and applies the same factor.  Both NULL: no dropout. */
 /* hp [B, T, 2, hidden]: the previous hidden state of each direction (forward: y[b, t-1, :hidden], reverse:
  * y[b, t+1, hidden:], zero at the sequence ends) — the operand of the W_hh weight-gradient GEMMs, in one launch. */
 int agnn_gru_hprev_f32(const float* y, int64_t B, int64_t T, int32_t hidden, float* hp, agnn_stream_t stream);

@@ -52,3 +52,42 @@ def test_other_hidden_sizes_use_library_rnn():
     assert not kernel_applicable(m)
     x = torch.randn(2, 5, 16, device=DEV)
     assert torch.allclose(gru_forward(m, x, False), m(x)[0])
+
+
+@pytest.mark.parametrize("B,T,I", [(3, 41, 64), (32, 120, 256)])
+def test_inter_layer_dropout_rides_with_the_recurrence_kernels(B, T, I):
+    """nn.GRU(dropout=p) between the two layers (models/cadence.py:249-251) as a factor the first layer's kernels apply
+    themselves: with a GIVEN 0 / (1 / (1 - p)) pattern, outputs and all gradients equal those of two one-layer GRUs with
+    `y0 * pattern` between them (torch.nn.GRU on the GPU as the yardstick); and in training mode about p of the first layer's
+    outputs really are dropped."""
+    from analysisgnn_amd.gru import _GRULayer, _stack_gru_params, gru_forward
+    torch.manual_seed(B + T)
+    m = torch.nn.GRU(I, 128, num_layers=2, batch_first=True, bidirectional=True, dropout=0.3).to(DEV)
+    x = torch.randn(B, T, I, device=DEV)
+    pattern = (torch.rand(B, T, 256, device=DEV) >= 0.3).float() / 0.7
+    # reference: the two layers as separate torch GRUs with the pattern applied in between
+    l0 = torch.nn.GRU(I, 128, batch_first=True, bidirectional=True).to(DEV)
+    l1 = torch.nn.GRU(256, 128, batch_first=True, bidirectional=True).to(DEV)
+    sd = m.state_dict()
+    l0.load_state_dict({k: sd[k] for k in l0.state_dict()})
+    l1.load_state_dict({k: sd[k.replace("_l0", "_l1")] for k in l1.state_dict()})
+    xr = x.clone().requires_grad_(True)
+    ref = l1(l0(xr)[0] * pattern)[0]
+    gout = torch.randn_like(ref)
+    (ref * gout).sum().backward()
+    xg = x.clone().requires_grad_(True)
+    st = _stack_gru_params(m)
+    y0 = _GRULayer.apply(xg, st[0], st[1], st[2], st[3], True, pattern)
+    out = _GRULayer.apply(y0, st[4], st[5], st[6], st[7], False, None)
+    assert_close(out, ref, 1e-4, "y")
+    (out * gout).sum().backward()
+    assert_close(xg.grad, xr.grad, 1e-4, "dx")
+    for n, p in m.named_parameters():
+        src = l0 if n.endswith("_l0") or n.endswith("_l0_reverse") else l1
+        pr = dict(src.named_parameters())[n.replace("_l1", "_l0")]
+        assert_close(p.grad, pr.grad, 1e-4, f"d{n}")
+    with torch.no_grad():
+        a = gru_forward(m.train(), x, training=True)
+        b = gru_forward(m, x, training=True)
+        c = gru_forward(m, x, training=False)
+    assert not torch.equal(a, b) and not torch.equal(a, c)
