@@ -194,8 +194,17 @@ class HeteroSAGEStack(nn.Module):
         index = hetero_index(edge_index_dict, {k: int(v.shape[0]) for k, v in x_dict.items()})
         self.last_index = index          # reused by the onset pooling that follows the encoder (models.py)
         index.prepare_trim(plan.e_keep)  # sampled batch: the row ends of all trimmed layers in one launch
+        # A layer followed by one that keeps NO edge (the last layer of the reference's default setup, see HeteroConv) is
+        # only read at the rows that layer keeps: the rows PyG's trim_to_layer would still carry for it as message sources
+        # are dead, so they are not computed — and the next layer's input is the whole matrix, not a slice of it (a slice's
+        # backward is a zero fill, a copy and a gradient add).
+        n_out = [dict(k) for k in plan.n_keep]
+        for i in range(self.num_layers - 2, -1, -1):
+            nxt = plan.e_keep[i + 1]
+            if nxt and all(v is not None and v <= 0 for v in nxt.values()):
+                n_out[i] = {t: min(n, n_out[i + 1].get(t, n)) for t, n in n_out[i].items()}
         for i, conv in enumerate(self.convs):
-            keep = plan.n_keep[i]
+            keep = n_out[i]
             x_dict = {k: v for k, v in x_dict.items()}
             x_dict = conv(x_dict, edge_index_dict, index, keep, plan.e_keep[i])
             if i < self.num_layers - 1:

@@ -28,6 +28,7 @@ clf = MultiTaskLoss(list(tasks)).to(dev)
 params, tight = dp.plan_parameters(torch.nn.ModuleDict({"m": model, "c": clf}))
 flat = dp.FlatGradBuffer(params, views=False, tight=tight)
 dp.enable_wgrad_overlap(wl in ("c2", "c2s"), "sequence")
+dp.defer_weight_grads(True)
 opt = dp.FlatAdamW(params, flat, lr=5e-3, weight_decay=5e-3)
 graph.index_cache_enabled = False
 lm = torch.stack([labels[t] for t in tasks])
