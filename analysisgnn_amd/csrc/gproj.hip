@@ -138,6 +138,7 @@ struct GpWTile {
   float4 w[4];
   float bias;
   int t, off, C, gc;                    // wave-uniform: tile index in its group, the group's column range, group index in the chunk
+  bool ok;                              // (persistent kernel) the slot holds a tile
 };
 
 __device__ __forceinline__ void gp_rowtile16(const GpArgs& p, const float4 (&af)[4], const GpWTile& r, float bias_on, int i, int q,
@@ -165,6 +166,9 @@ __device__ __forceinline__ void gp_rowtile16(const GpArgs& p, const float4 (&af)
   // A chunk wider than the LDS image: straight to global memory, 64-byte pieces.  Unconditional: a lane past the group's
   // classes computed class C - 1 again (its weight row was clamped) and a lane past the last row computed the last row
   // again, so writing to the clamped address repeats a correct value.
+#ifdef GP_ABL_ST
+  if (acc0[0] != 123.456f) return;
+#endif
   const int cs = c < r.C ? c : r.C - 1;
   float* op = p.out + r.off + cs;
 #pragma unroll
@@ -309,6 +313,181 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef GP_STAGE_WRITE
 }
 
+// ------------------------------------------------------------------------------------------
+// Whole-row forward, persistent and wave-specialised: one workgroup of 12 waves per CU walks 32-row blocks; the groups are
+// cut into ceil(G / 16) equal chunks (21 heads: 11 + 10 groups, 704 / 640 columns of `a`).  Same tiles and operand layout
+// as above.  What changes, and why (in-kernel stamps, scripts/gproj_stamps.py, profiles/r02_gproj.md):
+//   * vmcnt retires in program order, so in a wave that has the next chunk of `a` in flight (HBM, microseconds) every
+//     weight tile requested later (L2, a few hundred ns) is usable only after the whole chunk has landed: the tile loop of
+//     the kernel above runs at HBM latency once per chunk.  Here waves 8..11 only move `a` (8 rows each: load the next
+//     stage's chunk into registers, write it into the image between the two barriers of a stage) and waves 0..7 only
+//     fetch weight tiles (one tile ahead, two register sets), multiply and store; neither queue waits for the other;
+//   * tile rounds: with four groups per chunk the 53 16-class tiles of the 21 heads take 11 rounds of 8 waves; with two
+//     chunks they take 8 (6.6 would be a perfect deal).  The chunk image is 32 x 1028 floats, so a weight tile serves two
+//     row tiles and the logits go straight to global memory in 64-byte pieces;
+//   * the NEXT stage is the other chunk of this row block or the first chunk of the workgroup's next row block: only the
+//     very first chunk load of a workgroup is exposed.
+// A wave's tile slots of a chunk are the flat tiles chunk_begin + wave + 8t, t < n_slots (even); an empty slot repeats the
+// chunk's first tile (same values to the same addresses), which keeps the loop free of branches around memory operations.
+// ------------------------------------------------------------------------------------------
+constexpr int kGpLdA16 = 1028;          // floats per LDS row of a chunk (1024 + 4: 16-byte fragments of 16 rows, 16 bank groups)
+
+// Study builds (never the shipped library): -DGP_STAMPS records s_memtime per wave and phase (scripts/gproj_stamps.py reads
+// them through agnn_debug_gproj_stamps); -DGP_ABL_A / _W / _ST drop the `a` loads / the weight traffic / the logits stores.
+#ifdef GP_STAMPS
+__device__ unsigned long long g_gp_stamps[32 * 12 * 16];     // [workgroup < 32][wave][16]
+#define GP_STAMP() { if ((threadIdx.x & 63) == 0 && blockIdx.x < 32 && n_st_ < 16) g_gp_stamps[(blockIdx.x * 12 + (threadIdx.x >> 6)) * 16 + n_st_] = __builtin_amdgcn_s_memtime(); ++n_st_; }
+#else
+#define GP_STAMP()
+#endif
+#ifdef GP_ABL_W
+#define GP_WOFF(x) 0
+#else
+#define GP_WOFF(x) (x)
+#endif
+
+template <int NQ>                         // 256-column quarters per chunk (host: ceil(groups per chunk / 4))
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_gproj_fwd_rows32(GpArgs p, int CG, int n_chunks) {
+  [[maybe_unused]] int n_st_ = 0;
+  GP_STAMP()
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool mover = wave >= 8;
+  const int i = lane & 15, q = lane >> 4;
+  __shared__ __attribute__((aligned(16))) float sA[32 * kGpLdA16];
+  __shared__ uint32_t s_tiles[8][kGpMaxTiles16];
+  const int width = p.G * 64;
+  const int n_rb = static_cast<int>((p.n_rows + 31) >> 5);
+  if (static_cast<int>(blockIdx.x) >= n_rb) return;
+  // ---- movers: wave 8 + m owns rows 8m .. 8m + 7 of the block, lane l columns 4l .. 4l + 3 of each 256-column quarter j
+  // (named registers: an array indexed inside unrolled loops stayed in scratch here)
+#define GP_MV_DECL(r) float4 mv##r##0, mv##r##1, mv##r##2, mv##r##3;
+  GP_MV_DECL(0) GP_MV_DECL(1) GP_MV_DECL(2) GP_MV_DECL(3) GP_MV_DECL(4) GP_MV_DECL(5) GP_MV_DECL(6) GP_MV_DECL(7)
+#define GP_MV_LOAD1(r, j, rb, c)                                                                  \
+  if (NQ > (j)) {                                                                                 \
+    int64_t row_ = static_cast<int64_t>(rb) * 32 + 8 * (wave - 8) + (r);                          \
+    row_ = row_ < p.n_rows ? row_ : p.n_rows - 1;                                                 \
+    const int end_ = (c) + 1 < n_chunks ? ((c) + 1) * CG * 64 : width;                            \
+    const int col_ = (c) * CG * 64 + 256 * (j) + 4 * lane;                                        \
+    const int cc_ = col_ < end_ ? col_ : end_ - 4;  /* past the chunk: repeat a valid piece */     \
+    mv##r##j = *reinterpret_cast<const float4*>(p.a + row_ * p.ld_a + cc_);                       \
+  }
+#define GP_MV_WRITE1(r, j, rb, c) if (NQ > (j)) *reinterpret_cast<float4*>(&sA[(8 * (wave - 8) + (r)) * kGpLdA16 + 256 * (j) + 4 * lane]) = mv##r##j;
+#define GP_MV_ROW(M, r, rb, c) M(r, 0, rb, c) M(r, 1, rb, c) M(r, 2, rb, c) M(r, 3, rb, c)
+#define GP_MV_ALL(M, rb, c) { GP_MV_ROW(M, 0, rb, c) GP_MV_ROW(M, 1, rb, c) GP_MV_ROW(M, 2, rb, c) GP_MV_ROW(M, 3, rb, c) GP_MV_ROW(M, 4, rb, c) GP_MV_ROW(M, 5, rb, c) GP_MV_ROW(M, 6, rb, c) GP_MV_ROW(M, 7, rb, c) }
+#define GP_MOVE_LOAD(rb, c) GP_MV_ALL(GP_MV_LOAD1, rb, c)
+#define GP_MOVE_WRITE() GP_MV_ALL(GP_MV_WRITE1, 0, 0)
+  // Two loops, one per role, each with the same barriers (s_barrier counts waves, not program addresses): the registers of
+  // the two roles then share one allocation instead of adding up.
+  if (mover) {
+    int rb = blockIdx.x;
+    GP_MOVE_LOAD(rb, 0)
+    GP_STAMP()
+    GP_MOVE_WRITE()
+    __syncthreads();
+    GP_STAMP()
+    for (; rb < n_rb; rb += gridDim.x) {
+      for (int c = 0; c < n_chunks; ++c) {
+        const bool more = c + 1 < n_chunks || rb + static_cast<int>(gridDim.x) < n_rb;
+        if (!more) break;
+        const int nx_rb = c + 1 < n_chunks ? rb : rb + static_cast<int>(gridDim.x), nx_c = c + 1 < n_chunks ? c + 1 : 0;
+#ifdef GP_ABL_A
+        if (p.n_rows < 0)
+#endif
+        GP_MOVE_LOAD(nx_rb, nx_c)
+        GP_STAMP()
+        __syncthreads();                               // every tile of the chunk has read its fragments
+        GP_STAMP()
+        GP_MOVE_WRITE()
+        __syncthreads();
+        GP_STAMP()
+      }
+    }
+    return;
+  }
+  // ---- multipliers: the tile table
+  const int gl = lane < p.G ? lane : p.G - 1;
+  const int c0 = p.seg_off[gl], c1 = p.seg_off[gl + 1];
+  const int my_nt = lane < p.G ? ((c1 - c0 + 15) >> 4) : 0;
+  int start = 0, T = 0;
+  for (int g = 0; g < p.G; ++g) {
+    start = lane == g ? T : start;
+    T += __builtin_amdgcn_readlane(my_nt, g);
+  }
+  start = lane < p.G ? start : T;
+  for (int t = 0; t < my_nt; ++t) s_tiles[wave][start + t] = static_cast<uint32_t>(lane) | (static_cast<uint32_t>(t) << 8);
+  const float* bias_p = p.b != nullptr ? p.b : p.w;
+  const float bias_on = p.b != nullptr ? 1.f : 0.f;
+  // ---- multipliers: weight tiles, two register sets
+  GpWTile wA, wB;
+#define GP_W_FETCH(WT, CH, SL)                                                                       \
+  {                                                                                               \
+    const int cb_ = __builtin_amdgcn_readlane(start, CG * (CH) < 63 ? CG * (CH) : 63);              \
+    const int ce_ = __builtin_amdgcn_readlane(start, CG * ((CH) + 1) < 63 ? CG * ((CH) + 1) : 63);  \
+    const int n_ = cb_ + wave + 8 * (SL);                                                          \
+    const uint32_t ds_ = s_tiles[wave][n_ < ce_ ? n_ : (cb_ < T ? cb_ : T - 1)];                  \
+    const int g_ = __builtin_amdgcn_readfirstlane(static_cast<int>(ds_ & 0xffu));                 \
+    WT.t = __builtin_amdgcn_readfirstlane(static_cast<int>(ds_ >> 8));                             \
+    WT.off = __builtin_amdgcn_readlane(c0, g_);                                                    \
+    WT.C = __builtin_amdgcn_readlane(c1, g_) - WT.off;                                              \
+    WT.gc = g_ - (CH) * CG;                                                                         \
+    const int c_ = 16 * WT.t + i;                                                                  \
+    const int cc_ = c_ < WT.C ? c_ : WT.C - 1;                                                      \
+    const float4* wp_ = reinterpret_cast<const float4*>(p.w + static_cast<int64_t>(GP_WOFF(WT.off) + cc_) * 64 + 4 * q); \
+    WT.w[0] = wp_[0]; WT.w[1] = wp_[4]; WT.w[2] = wp_[8]; WT.w[3] = wp_[12];                          \
+    WT.bias = bias_p[WT.off + cc_];                                                                 \
+  }
+#define GP_TILE(WT)                                                                                \
+  {                                                                                               \
+    float4 f_[2][4];                                                                              \
+    _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                              \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u)                                               \
+        f_[rt][u] = *reinterpret_cast<const float4*>(&sA[(16 * rt + i) * kGpLdA16 + WT.gc * 64 + 16 * u + 4 * q]); \
+    _Pragma("unroll") for (int rt = 0; rt < 2; ++rt) gp_rowtile16(p, f_[rt], WT, bias_on, i, q, row0, 16 * rt, nullptr, 0); \
+  }
+  int rb = blockIdx.x;
+  GP_STAMP()
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // this wave's tile list is read back below
+  __builtin_amdgcn_wave_barrier();
+  GP_W_FETCH(wA, 0, 0)
+  __syncthreads();
+  GP_STAMP()
+  for (; rb < n_rb; rb += gridDim.x) {
+    const int64_t row0 = static_cast<int64_t>(rb) * 32;
+    for (int c = 0; c < n_chunks; ++c) {
+      const bool more = c + 1 < n_chunks || rb + static_cast<int>(gridDim.x) < n_rb;
+      const int nx_c = c + 1 < n_chunks ? c + 1 : 0;
+      const int cb = __builtin_amdgcn_readlane(start, CG * c < 63 ? CG * c : 63);
+      const int ce = __builtin_amdgcn_readlane(start, CG * (c + 1) < 63 ? CG * (c + 1) : 63);
+      const int n_slots = ((ce - cb + 15) >> 4) << 1;    // tiles per wave, rounded up to the two register sets
+      for (int t = 0; t < n_slots; t += 2) {
+        GP_W_FETCH(wB, c, t + 1)
+        GP_TILE(wA)
+        if (t + 2 < n_slots) GP_W_FETCH(wA, c, t + 2)
+        else GP_W_FETCH(wA, nx_c, 0)                     // the first tile of the next stage (weights do not depend on the rows)
+        GP_TILE(wB)
+      }
+      if (n_slots == 0) GP_W_FETCH(wA, nx_c, 0)           // (a chunk of class-less groups)
+      GP_STAMP()
+      if (more) {
+        __syncthreads();
+        GP_STAMP()
+        __syncthreads();                               // the movers have rewritten the image
+        GP_STAMP()
+      }
+    }
+  }
+#undef GP_MV_DECL
+#undef GP_MV_LOAD1
+#undef GP_MV_WRITE1
+#undef GP_MV_ROW
+#undef GP_MV_ALL
+#undef GP_MOVE_LOAD
+#undef GP_MOVE_WRITE
+#undef GP_W_FETCH
+#undef GP_TILE
+}
+
 template <int K>
 __global__ __launch_bounds__(256) void k_gproj_dx(GpArgs p) {
   constexpr int NT = K / 32;
@@ -425,13 +604,23 @@ __global__ __launch_bounds__(256) void k_gproj_dw(GpArgs p) {
   }
 }
 
-// A/B switch for scripts/bench_gproj.py: AGNN_GPROJ_FWD=1 -> the one-group-per-workgroup kernel instead of the whole-row one
+// A/B switch for scripts/bench_gproj.py: AGNN_GPROJ_FWD=1 -> one group per workgroup (round 1), 3 -> 64-row workgroups with
+// four-group chunks; anything else -> the persistent wave-specialised kernel
 int flags_fwd_variant() {
   static const int v = [] {
     const char* e = getenv("AGNN_GPROJ_FWD");
     return e ? atoi(e) : 0;
   }();
   return v;
+}
+
+int cu_count() {                          // compute units of the current device (one persistent workgroup each)
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    return v;
+  }();
+  return n;
 }
 
 struct Plan { int S, rows_per_slice; };
@@ -464,6 +653,12 @@ int check_common(const char* what, const void* a, int64_t ld_a, const void* w, c
 
 }  // namespace
 
+#ifdef GP_STAMPS
+extern "C" int agnn_debug_gproj_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gp_stamps), sizeof(g_gp_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int agnn_gproj_fwd_f32(const float* a, int64_t ld_a, const float* w, const float* b, const int32_t* seg_off,
                                   int32_t n_groups, int32_t K, int32_t n_tiles32, int64_t n_rows, float* out, int64_t ld_out,
                                   agnn_stream_t stream_) {
@@ -477,6 +672,16 @@ extern "C" int agnn_gproj_fwd_f32(const float* a, int64_t ld_a, const float* w, 
   p.n_row_tiles = static_cast<int32_t>((n_rows + 31) / 32);
   hipStream_t s = static_cast<hipStream_t>(stream_);
   if (K == 64 && n_groups <= 32 && n_tiles32 <= kGpMaxTiles16 / 2 && flags_fwd_variant() != 1) {   // whole-row kernel
+    if (flags_fwd_variant() != 3) {                     // AGNN_GPROJ_FWD=3: the 64-row kernel; =1: one group per workgroup
+      const int n_chunks = (n_groups + 15) / 16, CG = (n_groups + n_chunks - 1) / n_chunks, NQ = (CG + 3) / 4;
+      const int64_t n_rb = (n_rows + 31) / 32;
+      const dim3 grid(static_cast<unsigned>(n_rb < cu_count() ? n_rb : cu_count()));
+      if (NQ == 1) hipLaunchKernelGGL(k_gproj_fwd_rows32<1>, grid, dim3(768), 0, s, p, CG, n_chunks);
+      else if (NQ == 2) hipLaunchKernelGGL(k_gproj_fwd_rows32<2>, grid, dim3(768), 0, s, p, CG, n_chunks);
+      else if (NQ == 3) hipLaunchKernelGGL(k_gproj_fwd_rows32<3>, grid, dim3(768), 0, s, p, CG, n_chunks);
+      else hipLaunchKernelGGL(k_gproj_fwd_rows32<4>, grid, dim3(768), 0, s, p, CG, n_chunks);
+      return check_launch("gproj_fwd(rows32)");
+    }
     hipLaunchKernelGGL(k_gproj_fwd_rows, dim3(static_cast<unsigned>((n_rows + 63) / 64)), dim3(512), 0, s, p);
     return check_launch("gproj_fwd(rows)");
   }

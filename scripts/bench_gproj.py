@@ -2,7 +2,7 @@
 """The grouped head projection (21 task heads, C2 shapes): forward / input gradient / weight gradient timed on their own
 (HIP events around 20 back-to-back launches each) and checked against float64; also the thing to run under rocprofv3
 (--kernel-trace --stats, or --pmc ...).  AGNN_GPROJ_FWD selects the forward kernel (csrc/gproj.hip: 1 = one group per
-workgroup, 2 / 4 / 8 = whole rows with 1 / 2 / 4 waves per 16-row tile)."""
+workgroup, 3 = 64-row workgroups with four-group chunks, default = the persistent wave-specialised kernel)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
