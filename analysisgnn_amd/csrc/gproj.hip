@@ -604,11 +604,233 @@ __global__ __launch_bounds__(256) void k_gproj_dw(GpArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Whole-row input gradient (K = 64), persistent and wave-specialised like the forward above: one workgroup of 12 waves per
+// CU walks 32-row blocks.  da[n, g*64 + k] = sum_c dout[n, off_g + c] w[off_g + c, k].
+//   * waves 8..11 move `dout`: 8 rows each, whole rows (lane l takes columns 64j + l: 256 contiguous bytes per wave
+//     instruction, no alignment asked of the rows), held in registers while the block before is multiplied, then written
+//     into a 32 x ld_img image in which every group's classes start at a multiple of 16 floats and are zero-padded to a
+//     multiple of 16 (the image is zeroed once; the padding is never written).  A lane's columns — and so their places in
+//     the image — are the same for every row and block.
+//   * waves 0..7 multiply.  A unit of work is (group, 16-row tile), a step 16 of its classes: one ds_read_b128 gives lane
+//     (i = lane & 15, q = lane >> 4) the classes 4q .. 4q + 3 of row i, four 16-byte loads give it w[class 4q + e][4i .. 4i+3],
+//     and MFMA (e, t) multiplies "k = class 4q + e" with "column 4i + t": the 16 MFMAs of a step cover all 64 columns, and
+//     the four accumulators of a lane are four CONSECUTIVE columns, so the tile leaves as 16-byte stores, 256 contiguous
+//     bytes per row.  Units are handed out largest group first from an LDS counter (the class counts are ragged: 1 .. 12
+//     steps, 13 of the 21 heads have one).  A wave's steps form ONE stream across its units: the weights of a step are
+//     requested two steps ahead (three register sets, handed on by register moves), the next unit is taken from the counter
+//     when the last step of the one before is requested — a unit start costs no memory latency.
+// The kernel moves 40 MB in and 86 MB out for 1.7 GFLOP: it is bound by the HBM stream, not by the MFMAs.
+// ------------------------------------------------------------------------------------------
+constexpr int kGpDxLd = 1092;           // floats per image row (32 x 1092 x 4 = 139 776 bytes; 273 16-byte slots: odd).  A constant, so
+                                        // that the movers' 8 rows are immediate offsets of one address register per column piece
+
+struct GdStep {                           // wave-uniform description of one step, travelling with its weight registers
+  int g, rt, s, C, po;                    // group, row tile, step, classes of the group, place of the group in the image
+  bool last, valid;
+};
+
+template <int NJ>                         // 64-column pieces per row of dout (host: ceil(sum_c / 64))
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_gproj_dx_rows(GpArgs p) {
+  constexpr int ld_img = kGpDxLd;
+  [[maybe_unused]] int n_st_ = 0;
+  GP_STAMP()
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool mover = wave >= 8;
+  __shared__ __attribute__((aligned(16))) float sD[32 * kGpDxLd];
+  __shared__ uint32_t s_units[64];
+  __shared__ int s_next;
+  __shared__ int s_place[1024];                           // column of dout -> its place in an image row
+  const int n_rb = static_cast<int>((p.n_rows + 31) >> 5);
+  if (static_cast<int>(blockIdx.x) >= n_rb) return;
+  const int gl = lane < p.G ? lane : p.G - 1;
+  const int c0 = p.seg_off[gl], c1 = p.seg_off[gl + 1];     // requested before the movers' rows: vmcnt retires in order
+  // ---- movers' registers: row r (of the wave's 8), piece j: column 64j + lane
+#define GD_DECL(r) float mv##r##0, mv##r##1, mv##r##2, mv##r##3, mv##r##4, mv##r##5, mv##r##6, mv##r##7, mv##r##8, mv##r##9, \
+                         mv##r##10, mv##r##11, mv##r##12, mv##r##13, mv##r##14, mv##r##15;
+  GD_DECL(0) GD_DECL(1) GD_DECL(2) GD_DECL(3) GD_DECL(4) GD_DECL(5) GD_DECL(6) GD_DECL(7)
+#define GD_LOAD1(r, j, rb)                                                                        \
+  if (NJ > (j)) {                                                                                 \
+    int64_t row_ = static_cast<int64_t>(rb) * 32 + 8 * (wave - 8) + (r);                          \
+    row_ = row_ < p.n_rows ? row_ : p.n_rows - 1;                                                 \
+    const int col_ = 64 * (j) + lane;                                                             \
+    mv##r##j = p.dout[row_ * p.ld_out + (col_ < p.sum_c ? col_ : p.sum_c - 1)];                   \
+  }
+#define GD_WRITE1(r, j, rb) if (NJ > (j)) sDw[(r) * ld_img + pc##j] = mv##r##j;   /* no per-lane condition: see GD_PC */
+#define GD_ROW(M, r, rb) M(r, 0, rb) M(r, 1, rb) M(r, 2, rb) M(r, 3, rb) M(r, 4, rb) M(r, 5, rb) M(r, 6, rb) M(r, 7, rb) \
+                         M(r, 8, rb) M(r, 9, rb) M(r, 10, rb) M(r, 11, rb) M(r, 12, rb) M(r, 13, rb) M(r, 14, rb) M(r, 15, rb)
+#define GD_ALL(M, rb) { GD_ROW(M, 0, rb) GD_ROW(M, 1, rb) GD_ROW(M, 2, rb) GD_ROW(M, 3, rb) GD_ROW(M, 4, rb) GD_ROW(M, 5, rb) GD_ROW(M, 6, rb) GD_ROW(M, 7, rb) }
+  if (mover) GD_ALL(GD_LOAD1, blockIdx.x)                // on their way during everything below
+  // ---- zero the image once (the padding of every group stays zero)
+  for (int e = threadIdx.x * 4; e < 32 * ld_img; e += 768 * 4) *reinterpret_cast<float4*>(&sD[e]) = make_float4(0.f, 0.f, 0.f, 0.f);
+  // ---- group table in lanes: lane g holds group g's class range, its 16-class steps, its place in the image
+  const int my_steps = lane < p.G ? ((c1 - c0 + 15) >> 4) : 0;
+  int poff = 0, tot = 0, rank = 0;
+  for (int g = 0; g < p.G; ++g) {
+    const int sg = __builtin_amdgcn_readlane(my_steps, g);
+    poff = lane == g ? tot : poff;
+    tot += 16 * sg;
+    rank += (sg > my_steps || (sg == my_steps && g < lane)) ? 1 : 0;
+  }
+  // ---- every column's place in the image row, worked out once by all 768 threads
+  // (a column's place = the column + the padding of every group that ends at or before it)
+  const int my_pad = 16 * my_steps - (lane < p.G ? c1 - c0 : 0);
+  // (uniform trip count: readlane of a lane that sits out a divergent loop is undefined)
+  for (int base = 0; base < p.sum_c; base += 768) {
+    const int col = base + static_cast<int>(threadIdx.x);
+    int pl = col;
+    for (int h = 0; h < p.G; ++h) pl += __builtin_amdgcn_readlane(c1, h) <= col ? __builtin_amdgcn_readlane(my_pad, h) : 0;
+    if (col < p.sum_c) s_place[col] = pl;
+  }
+  if (mover) {
+    float* sDw = &sD[8 * (wave - 8) * ld_img];            // this wave's 8 rows
+    if (wave == 8 && lane == 0) s_next = 0;
+    __syncthreads();                                     // the image is zero, the places are known
+    // this lane's columns 64j + lane; one past the row: the last float of the image row, which nothing reads
+#define GD_PC(j)                                                                                  \
+  int pc##j = ld_img - 1;                                                                         \
+  if (NJ > (j)) {                                                                                 \
+    pc##j = 64 * (j) + lane < p.sum_c ? s_place[64 * (j) + lane] : ld_img - 1;                    \
+    __builtin_assume(pc##j >= 0 && pc##j < ld_img);        /* (lets the row offsets become immediate offsets of the LDS writes) */ \
+  }
+    GD_PC(0) GD_PC(1) GD_PC(2) GD_PC(3) GD_PC(4) GD_PC(5) GD_PC(6) GD_PC(7)
+    GD_PC(8) GD_PC(9) GD_PC(10) GD_PC(11) GD_PC(12) GD_PC(13) GD_PC(14) GD_PC(15)
+    GD_ALL(GD_WRITE1, 0)
+    __syncthreads();                                     // the first block is in the image
+    GP_STAMP()
+    for (int rb = blockIdx.x; rb + static_cast<int>(gridDim.x) < n_rb; rb += gridDim.x) {
+      GD_ALL(GD_LOAD1, rb + gridDim.x)
+      GP_STAMP()
+      __syncthreads();                                   // every unit of the block has been multiplied
+      GP_STAMP()
+      GD_ALL(GD_WRITE1, 0)
+      if (wave == 8 && lane == 0) s_next = 0;
+      __syncthreads();
+      GP_STAMP()
+    }
+    return;
+  }
+  // ---- multipliers
+  const int i = lane & 15, q = lane >> 4;
+  const int n_units = 2 * p.G;
+  if (wave == 0 && lane < p.G) {                         // largest group first
+    s_units[2 * rank] = static_cast<uint32_t>(lane);
+    s_units[2 * rank + 1] = static_cast<uint32_t>(lane) | 256u;
+  }
+  __syncthreads();
+  __syncthreads();
+  GP_STAMP()
+  for (int rb = blockIdx.x; rb < n_rb; rb += gridDim.x) {
+    const int64_t row0 = static_cast<int64_t>(rb) * 32;
+    // the request stream: unit (fg, frt) with fsteps steps, fs the next one to request
+    int fg = 0, frt = 0, foff = 0, fC = 0, fpo = 0, fsteps = 1, fs = 0;
+    bool fvalid = false;
+#define GD_GRAB()                                                                                 \
+  {                                                                                               \
+    int u_ = 0;                                                                                   \
+    if (lane == 0) u_ = atomicAdd(&s_next, 1);                                                    \
+    u_ = __builtin_amdgcn_readfirstlane(u_);                                                      \
+    fvalid = u_ < n_units;                                                                        \
+    const uint32_t ds_ = s_units[fvalid ? u_ : 0];                                                \
+    fg = __builtin_amdgcn_readfirstlane(static_cast<int>(ds_ & 0xffu));                           \
+    frt = __builtin_amdgcn_readfirstlane(static_cast<int>(ds_ >> 8));                             \
+    foff = __builtin_amdgcn_readlane(c0, fg);                                                     \
+    fC = __builtin_amdgcn_readlane(c1, fg) - foff;                                                \
+    fpo = __builtin_amdgcn_readlane(poff, fg);                                                    \
+    fsteps = (fC + 15) >> 4;                                                                      \
+    fsteps = fsteps > 0 ? fsteps : 1;                      /* a class-less group still writes its zeros */ \
+    fs = 0;                                                                                       \
+  }
+    // request the weights of the stream's next step into (D, B0 .. B3); then move the stream on.  Always loads (from a
+    // clamped, valid row): no branch around memory operations.
+#define GD_NEXT(D, B)                                                                             \
+  {                                                                                               \
+    D.g = fg; D.rt = frt; D.s = fs; D.C = fC; D.po = fpo; D.last = fs + 1 == fsteps; D.valid = fvalid; \
+    const int k_ = 16 * fs + 4 * q;                                                               \
+    const int hi_ = fC > 0 ? fC - 1 : 0;                                                          \
+    const float* wg_ = p.w + 4 * i;                                                               \
+    int r0_ = GP_WOFF(foff) + (k_ < hi_ ? k_ : hi_), r1_ = GP_WOFF(foff) + (k_ + 1 < hi_ ? k_ + 1 : hi_);         \
+    int r2_ = GP_WOFF(foff) + (k_ + 2 < hi_ ? k_ + 2 : hi_), r3_ = GP_WOFF(foff) + (k_ + 3 < hi_ ? k_ + 3 : hi_); \
+    r0_ = r0_ < p.sum_c ? r0_ : p.sum_c - 1; r1_ = r1_ < p.sum_c ? r1_ : p.sum_c - 1;             \
+    r2_ = r2_ < p.sum_c ? r2_ : p.sum_c - 1; r3_ = r3_ < p.sum_c ? r3_ : p.sum_c - 1;             \
+    B##0 = *reinterpret_cast<const float4*>(wg_ + static_cast<int64_t>(r0_) * 64);                \
+    B##1 = *reinterpret_cast<const float4*>(wg_ + static_cast<int64_t>(r1_) * 64);                \
+    B##2 = *reinterpret_cast<const float4*>(wg_ + static_cast<int64_t>(r2_) * 64);                \
+    B##3 = *reinterpret_cast<const float4*>(wg_ + static_cast<int64_t>(r3_) * 64);                \
+    ++fs;                                                                                         \
+    if (fvalid && fs == fsteps) GD_GRAB()                                                         \
+  }
+#define GD_MMA1(av, B)                                                                            \
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, B.x, acc0, 0, 0, 0);                            \
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, B.y, acc1, 0, 0, 0);                            \
+  acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, B.z, acc2, 0, 0, 0);                            \
+  acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, B.w, acc3, 0, 0, 0);
+    GdStep d0, d1, d2;
+    float4 x0, x1, x2, x3, y0, y1, y2, y3, z0, z1, z2, z3;   // the weights of steps d0 (being multiplied), d1, d2
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    GD_GRAB()
+    GD_NEXT(d1, y)
+    GD_NEXT(d2, z)
+    // the fragment of `dout` one step ahead (a class-less group's place in the image is the next group's: zero instead)
+#define GD_FRAG(D) (D.C > 0 ? *reinterpret_cast<const float4*>(&sD[(16 * D.rt + i) * ld_img + D.po + 16 * D.s + 4 * q]) : make_float4(0.f, 0.f, 0.f, 0.f))
+    float4 an = GD_FRAG(d1);
+    while (d1.valid) {
+      d0 = d1; x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+      d1 = d2; y0 = z0; y1 = z1; y2 = z2; y3 = z3;
+      const float4 a = an;
+      an = GD_FRAG(d1);
+      GD_NEXT(d2, z)
+      if (d0.s == 0) { acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = acc0; acc2 = acc0; acc3 = acc0; }
+      GD_MMA1(a.x, x0) GD_MMA1(a.y, x1) GD_MMA1(a.z, x2) GD_MMA1(a.w, x3)
+      if (d0.last) {
+        // lane (i, q): rows 4q + r of the tile, columns 4i .. 4i + 3 of the group.  A row past the end was a copy of the
+        // last row in the image: the same values go to the last row again.
+#ifdef GP_ABL_ST
+        if (acc0[0] != 123.456f) continue;
+#endif
+        float* dp = p.da + d0.g * 64 + 4 * i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int64_t ro = row0 + 16 * d0.rt + 4 * q + r;
+          ro = ro < p.n_rows ? ro : p.n_rows - 1;
+          *reinterpret_cast<float4*>(dp + ro * p.ld_da) = make_float4(acc0[r], acc1[r], acc2[r], acc3[r]);
+        }
+      }
+    }
+    GP_STAMP()
+    if (rb + static_cast<int>(gridDim.x) < n_rb) {
+      __syncthreads();
+      GP_STAMP()
+      __syncthreads();                                   // the movers have rewritten the image and reset the counter
+      GP_STAMP()
+    }
+  }
+#undef GD_DECL
+#undef GD_LOAD1
+#undef GD_WRITE1
+#undef GD_ROW
+#undef GD_ALL
+#undef GD_PC
+#undef GD_GRAB
+#undef GD_NEXT
+#undef GD_MMA1
+#undef GD_FRAG
+}
+
 // A/B switch for scripts/bench_gproj.py: AGNN_GPROJ_FWD=1 -> one group per workgroup (round 1), 3 -> 64-row workgroups with
 // four-group chunks; anything else -> the persistent wave-specialised kernel
 int flags_fwd_variant() {
   static const int v = [] {
     const char* e = getenv("AGNN_GPROJ_FWD");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
+int flags_dx_variant() {                   // AGNN_GPROJ_DX=1: the one-wave-per-(row tile, group) kernel
+  static const int v = [] {
+    const char* e = getenv("AGNN_GPROJ_DX");
     return e ? atoi(e) : 0;
   }();
   return v;
@@ -715,12 +937,27 @@ extern "C" int agnn_gproj_bwd_f32(const float* dout, int64_t ld_dout, const floa
   if (da != nullptr) {
     if (ld_da < static_cast<int64_t>(n_groups) * K) return fail(AGNN_EINVAL, "gproj_bwd: ld_da smaller than groups*K");
     p.da = da; p.ld_da = ld_da;
+    const int ld_img = sum_c + 15 * n_groups + 4;          // at most: every group padded to 16 classes, + the dump slot
+    const bool rows_ok = K == 64 && n_groups <= 32 && sum_c >= 1 && sum_c <= 1024 && ld_img <= kGpDxLd && aligned16(da) && (ld_da & 3) == 0;
+    if (rows_ok && flags_dx_variant() != 1) {            // whole-row kernel
+      const int64_t n_rb = (n_rows + 31) / 32;
+      const dim3 grid(static_cast<unsigned>(n_rb < cu_count() ? n_rb : cu_count()));
+      switch ((sum_c + 63) / 64) {
+#define GD_CASE(n) case n: hipLaunchKernelGGL(k_gproj_dx_rows<n>, grid, dim3(768), 0, s, p); break;
+        GD_CASE(1) GD_CASE(2) GD_CASE(3) GD_CASE(4) GD_CASE(5) GD_CASE(6) GD_CASE(7) GD_CASE(8) GD_CASE(9) GD_CASE(10)
+        GD_CASE(11) GD_CASE(12) GD_CASE(13) GD_CASE(14) GD_CASE(15)
+        default: hipLaunchKernelGGL(k_gproj_dx_rows<16>, grid, dim3(768), 0, s, p); break;
+#undef GD_CASE
+      }
+      if (int rc = check_launch("gproj_dx(rows)")) return rc;
+    } else {
     const int64_t items = static_cast<int64_t>(p.n_row_tiles) * n_groups;
     const dim3 grid(static_cast<unsigned>((items + 3) / 4));
     if (K == 32) hipLaunchKernelGGL(k_gproj_dx<32>, grid, dim3(256), 0, s, p);
     else if (K == 64) hipLaunchKernelGGL(k_gproj_dx<64>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(k_gproj_dx<128>, grid, dim3(256), 0, s, p);
     if (int rc = check_launch("gproj_dx")) return rc;
+    }
   }
   if (dw != nullptr) {
     const size_t need = agnn_gproj_workspace_bytes(n_rows, sum_c, K, n_tiles32);

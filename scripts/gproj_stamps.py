@@ -19,9 +19,16 @@ N, K = int(os.environ.get("N", "16000")), 64
 a = torch.randn(N, len(classes) * K, device=dev)
 w = torch.randn(offs[-1], K, device=dev) * 0.1
 b = torch.randn(offs[-1], device=dev)
-with torch.no_grad():
+WHAT = os.environ.get("WHAT", "fwd")                      # fwd | dx
+if WHAT == "fwd":
+    with torch.no_grad():
+        for _ in range(3):
+            grouped_projection(a, w, b, offs, K)
+else:
+    a.requires_grad_(True)
+    g = torch.randn(N, offs[-1], device=dev)
     for _ in range(3):
-        grouped_projection(a, w, b, offs, K)
+        grouped_projection(a, w, b, offs, K).backward(g)
 torch.cuda.synchronize()
 lib = ctypes.CDLL(os.environ["AGNN_LIB"])
 buf = (ctypes.c_ulonglong * (32 * 12 * 16))()
@@ -30,11 +37,12 @@ st = np.frombuffer(buf, dtype=np.uint64).reshape(32, 12, 16).astype(np.int64)   
 n = int((st[0, 0] > 0).sum())
 nm = int((st[0, 8] > 0).sum())
 print(f"s_memtime ticks (core clocks), median over 32 workgroups; multipliers (waves 0..7): {n} stamps, movers (8..11): {nm}")
-names = ["prologue", "first image"] + [f"stage {k // 3}: {('tiles', 'barrier', 'image rewrite')[k % 3]}" for k in range(n - 3)]
+first = ["prologue", "first image"] if WHAT == "fwd" else ["prologue + first image"]
+names = first + [f"stage {k // 3}: {('tiles', 'barrier', 'image rewrite')[k % 3]}" for k in range(n - 1 - len(first))]
 d = np.diff(st[:, :8, :n], axis=2)
 for k in range(n - 1):
     print(f"  {names[k]:24s} " + " ".join(f"{np.median(d[:, w, k]):7.0f}" for w in range(8)))
-names = ["prologue", "first image"] + [f"stage {k // 3}: {('loads issued', 'barrier', 'image rewrite')[k % 3]}" for k in range(nm - 3)]
+names = first + [f"stage {k // 3}: {('loads issued', 'barrier', 'image rewrite')[k % 3]}" for k in range(nm - 1 - len(first))]
 d = np.diff(st[:, 8:, :nm], axis=2)
 for k in range(nm - 1):
     print(f"  {names[k]:24s} " + " ".join(f"{np.median(d[:, w, k]):7.0f}" for w in range(4)))
