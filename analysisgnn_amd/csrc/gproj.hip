@@ -644,8 +644,6 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   __shared__ int s_place[1024];                           // column of dout -> its place in an image row
   const int n_rb = static_cast<int>((p.n_rows + 31) >> 5);
   if (static_cast<int>(blockIdx.x) >= n_rb) return;
-  const int gl = lane < p.G ? lane : p.G - 1;
-  const int c0 = p.seg_off[gl], c1 = p.seg_off[gl + 1];     // requested before the movers' rows: vmcnt retires in order
   // ---- movers' registers: row r (of the wave's 8), piece j: column 64j + lane
 #define GD_DECL(r) float mv##r##0, mv##r##1, mv##r##2, mv##r##3, mv##r##4, mv##r##5, mv##r##6, mv##r##7, mv##r##8, mv##r##9, \
                          mv##r##10, mv##r##11, mv##r##12, mv##r##13, mv##r##14, mv##r##15;
@@ -654,38 +652,20 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   if (NJ > (j)) {                                                                                 \
     int64_t row_ = static_cast<int64_t>(rb) * 32 + 8 * (wave - 8) + (r);                          \
     row_ = row_ < p.n_rows ? row_ : p.n_rows - 1;                                                 \
-    const int col_ = 64 * (j) + lane;                                                             \
-    mv##r##j = p.dout[row_ * p.ld_out + (col_ < p.sum_c ? col_ : p.sum_c - 1)];                   \
+    const float* rp_ = p.dout + row_ * p.ld_out;          /* uniform base + one 32-bit lane offset (+ immediate) */ \
+    mv##r##j = (j) + 1 < NJ ? rp_[ulane + 64u * (j)] : rp_[ulast];                                \
   }
 #define GD_WRITE1(r, j, rb) if (NJ > (j)) sDw[(r) * ld_img + pc##j] = mv##r##j;   /* no per-lane condition: see GD_PC */
 #define GD_ROW(M, r, rb) M(r, 0, rb) M(r, 1, rb) M(r, 2, rb) M(r, 3, rb) M(r, 4, rb) M(r, 5, rb) M(r, 6, rb) M(r, 7, rb) \
                          M(r, 8, rb) M(r, 9, rb) M(r, 10, rb) M(r, 11, rb) M(r, 12, rb) M(r, 13, rb) M(r, 14, rb) M(r, 15, rb)
 #define GD_ALL(M, rb) { GD_ROW(M, 0, rb) GD_ROW(M, 1, rb) GD_ROW(M, 2, rb) GD_ROW(M, 3, rb) GD_ROW(M, 4, rb) GD_ROW(M, 5, rb) GD_ROW(M, 6, rb) GD_ROW(M, 7, rb) }
-  if (mover) GD_ALL(GD_LOAD1, blockIdx.x)                // on their way during everything below
-  // ---- zero the image once (the padding of every group stays zero)
-  for (int e = threadIdx.x * 4; e < 32 * ld_img; e += 768 * 4) *reinterpret_cast<float4*>(&sD[e]) = make_float4(0.f, 0.f, 0.f, 0.f);
-  // ---- group table in lanes: lane g holds group g's class range, its 16-class steps, its place in the image
-  const int my_steps = lane < p.G ? ((c1 - c0 + 15) >> 4) : 0;
-  int poff = 0, tot = 0, rank = 0;
-  for (int g = 0; g < p.G; ++g) {
-    const int sg = __builtin_amdgcn_readlane(my_steps, g);
-    poff = lane == g ? tot : poff;
-    tot += 16 * sg;
-    rank += (sg > my_steps || (sg == my_steps && g < lane)) ? 1 : 0;
-  }
-  // ---- every column's place in the image row, worked out once by all 768 threads
-  // (a column's place = the column + the padding of every group that ends at or before it)
-  const int my_pad = 16 * my_steps - (lane < p.G ? c1 - c0 : 0);
-  // (uniform trip count: readlane of a lane that sits out a divergent loop is undefined)
-  for (int base = 0; base < p.sum_c; base += 768) {
-    const int col = base + static_cast<int>(threadIdx.x);
-    int pl = col;
-    for (int h = 0; h < p.G; ++h) pl += __builtin_amdgcn_readlane(c1, h) <= col ? __builtin_amdgcn_readlane(my_pad, h) : 0;
-    if (col < p.sum_c) s_place[col] = pl;
-  }
+  const unsigned ulane = lane;                             // only the last piece of a row can run past its end
+  const unsigned ulast = 64 * (NJ - 1) + lane < p.sum_c ? 64u * (NJ - 1) + ulane : static_cast<unsigned>(p.sum_c - 1);
+  // The movers do nothing but move: their first block is on its way while the other eight waves prepare the image and the
+  // tables (anything more here and the compiler parks the rows in scratch, one wait per load).
   if (mover) {
+    GD_ALL(GD_LOAD1, blockIdx.x)
     float* sDw = &sD[8 * (wave - 8) * ld_img];            // this wave's 8 rows
-    if (wave == 8 && lane == 0) s_next = 0;
     __syncthreads();                                     // the image is zero, the places are known
     // this lane's columns 64j + lane; one past the row: the last float of the image row, which nothing reads
 #define GD_PC(j)                                                                                  \
@@ -711,9 +691,33 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
     return;
   }
+  // ---- zero the image once (the padding of every group stays zero)
+  for (int e = threadIdx.x * 4; e < 32 * ld_img; e += 512 * 4) *reinterpret_cast<float4*>(&sD[e]) = make_float4(0.f, 0.f, 0.f, 0.f);
+  // ---- group table in lanes: lane g holds group g's class range, its 16-class steps, its place in the image
+  const int gl = lane < p.G ? lane : p.G - 1;
+  const int c0 = p.seg_off[gl], c1 = p.seg_off[gl + 1];
+  const int my_steps = lane < p.G ? ((c1 - c0 + 15) >> 4) : 0;
+  int poff = 0, tot = 0, rank = 0;
+  for (int g = 0; g < p.G; ++g) {
+    const int sg = __builtin_amdgcn_readlane(my_steps, g);
+    poff = lane == g ? tot : poff;
+    tot += 16 * sg;
+    rank += (sg > my_steps || (sg == my_steps && g < lane)) ? 1 : 0;
+  }
+  // ---- every column's place in the image row, worked out once by the 512 threads
+  // (a column's place = the column + the padding of every group that ends at or before it)
+  const int my_pad = 16 * my_steps - (lane < p.G ? c1 - c0 : 0);
+  // (uniform trip count: readlane of a lane that sits out a divergent loop is undefined)
+  for (int base = 0; base < p.sum_c; base += 512) {
+    const int col = base + static_cast<int>(threadIdx.x);
+    int pl = col;
+    for (int h = 0; h < p.G; ++h) pl += __builtin_amdgcn_readlane(c1, h) <= col ? __builtin_amdgcn_readlane(my_pad, h) : 0;
+    if (col < p.sum_c) s_place[col] = pl;
+  }
   // ---- multipliers
   const int i = lane & 15, q = lane >> 4;
   const int n_units = 2 * p.G;
+  if (wave == 0 && lane == 0) s_next = 0;
   if (wave == 0 && lane < p.G) {                         // largest group first
     s_units[2 * rank] = static_cast<uint32_t>(lane);
     s_units[2 * rank + 1] = static_cast<uint32_t>(lane) | 256u;
@@ -767,36 +771,46 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, B.z, acc2, 0, 0, 0);                            \
   acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, B.w, acc3, 0, 0, 0);
     GdStep d0, d1, d2;
-    float4 x0, x1, x2, x3, y0, y1, y2, y3, z0, z1, z2, z3;   // the weights of steps d0 (being multiplied), d1, d2
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-    GD_GRAB()
-    GD_NEXT(d1, y)
-    GD_NEXT(d2, z)
+    float4 x0, x1, x2, x3, y0, y1, y2, y3, z0, z1, z2, z3;   // three weight register sets in rotation (no register moves: a
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;   // move would wait for the newest request)
     // the fragment of `dout` one step ahead (a class-less group's place in the image is the next group's: zero instead)
 #define GD_FRAG(D) (D.C > 0 ? *reinterpret_cast<const float4*>(&sD[(16 * D.rt + i) * ld_img + D.po + 16 * D.s + 4 * q]) : make_float4(0.f, 0.f, 0.f, 0.f))
-    float4 an = GD_FRAG(d1);
-    while (d1.valid) {
-      d0 = d1; x0 = y0; x1 = y1; x2 = y2; x3 = y3;
-      d1 = d2; y0 = z0; y1 = z1; y2 = z2; y3 = z3;
-      const float4 a = an;
-      an = GD_FRAG(d1);
-      GD_NEXT(d2, z)
-      if (d0.s == 0) { acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = acc0; acc2 = acc0; acc3 = acc0; }
-      GD_MMA1(a.x, x0) GD_MMA1(a.y, x1) GD_MMA1(a.z, x2) GD_MMA1(a.w, x3)
-      if (d0.last) {
-        // lane (i, q): rows 4q + r of the tile, columns 4i .. 4i + 3 of the group.  A row past the end was a copy of the
-        // last row in the image: the same values go to the last row again.
+    // one step: multiply with (DC, BC); (DN, ..) is the step after it; the step after that is requested into (DF, BF), the
+    // set the step before this one used
+#define GD_STEP(DC, BC, DN, DF, BF)                                                               \
+  {                                                                                               \
+    GD_NEXT(DF, BF)                                                                               \
+    const float4 a = an;                                                                          \
+    an = GD_FRAG(DN);                                                                             \
+    if (DC.s == 0) { acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = acc0; acc2 = acc0; acc3 = acc0; }    \
+    GD_MMA1(a.x, BC##0) GD_MMA1(a.y, BC##1) GD_MMA1(a.z, BC##2) GD_MMA1(a.w, BC##3)                \
+    if (DC.last) {                                                                                \
+      /* lane (i, q): rows 4q + r of the tile, columns 4i .. 4i + 3 of the group.  A row past the end was a copy of the */ \
+      /* last row in the image: the same values go to the last row again. */                       \
+      float* dp = p.da + DC.g * 64 + 4 * i;                                                       \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                             \
+        int64_t ro = row0 + 16 * DC.rt + 4 * q + r;                                               \
+        ro = ro < p.n_rows ? ro : p.n_rows - 1;                                                   \
+        GD_STORE(reinterpret_cast<float4*>(dp + ro * p.ld_da), make_float4(acc0[r], acc1[r], acc2[r], acc3[r])) \
+      }                                                                                           \
+    }                                                                                             \
+  }
 #ifdef GP_ABL_ST
-        if (acc0[0] != 123.456f) continue;
+#define GD_STORE(ptr, v) if (acc0[0] == 123.456f) *(ptr) = (v);
+#else
+#define GD_STORE(ptr, v) *(ptr) = (v);
 #endif
-        float* dp = p.da + d0.g * 64 + 4 * i;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int64_t ro = row0 + 16 * d0.rt + 4 * q + r;
-          ro = ro < p.n_rows ? ro : p.n_rows - 1;
-          *reinterpret_cast<float4*>(dp + ro * p.ld_da) = make_float4(acc0[r], acc1[r], acc2[r], acc3[r]);
-        }
-      }
+    GD_GRAB()
+    GD_NEXT(d0, x)
+    GD_NEXT(d1, y)
+    float4 an = GD_FRAG(d0);
+    for (;;) {
+      if (!d0.valid) break;
+      GD_STEP(d0, x, d1, d2, z)
+      if (!d1.valid) break;
+      GD_STEP(d1, y, d2, d0, x)
+      if (!d2.valid) break;
+      GD_STEP(d2, z, d0, d1, y)
     }
     GP_STAMP()
     if (rb + static_cast<int>(gridDim.x) < n_rb) {
@@ -816,6 +830,8 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #undef GD_NEXT
 #undef GD_MMA1
 #undef GD_FRAG
+#undef GD_STEP
+#undef GD_STORE
 }
 
 // A/B switch for scripts/bench_gproj.py: AGNN_GPROJ_FWD=1 -> one group per workgroup (round 1), 3 -> 64-row workgroups with
