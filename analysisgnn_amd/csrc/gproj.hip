@@ -578,16 +578,22 @@ __global__ __launch_bounds__(256) void k_gproj_dw(GpArgs p) {
       bs += avv[u];
     }
   };
-  // two register sets in rotation: the next 16 rows are in flight during the MFMAs of the current 16
+  // three register sets in rotation: the 32 rows after the current 16 are in flight during its MFMAs (two waves per SIMD and
+  // 1024 cycles of MFMA per set: one set ahead covered half of an HBM round trip).  A fetch past the slice reads the last
+  // row with a zero mask: no branch around the loads.
   if (r0 < r1) {
-    float a0[8], b0[8][NT], a1[8], b1[8][NT];
+    float a0[8], b0[8][NT], a1[8], b1[8][NT], a2[8], b2[8][NT];
     fetch(r0, a0, b0);
-    for (int base = r0; base < r1; base += 32) {
-      if (base + 16 < r1) fetch(base + 16, a1, b1);
+    fetch(r0 + 16, a1, b1);
+    for (int base = r0; base < r1; base += 48) {
+      fetch(base + 32, a2, b2);
       mma(a0, b0);
       if (base + 16 >= r1) break;
-      if (base + 32 < r1) fetch(base + 32, a0, b0);
+      fetch(base + 48, a0, b0);
       mma(a1, b1);
+      if (base + 32 >= r1) break;
+      fetch(base + 64, a1, b1);
+      mma(a2, b2);
     }
   }
   float* slab = p.slab + (static_cast<int64_t>(slice) * p.sum_c + off) * K;
@@ -864,7 +870,8 @@ int cu_count() {                          // compute units of the current device
 struct Plan { int S, rows_per_slice; };
 
 Plan make_plan(int64_t n, int n_tiles32) {
-  int64_t S = (2048 + n_tiles32 - 1) / n_tiles32;   // ~2 waves per SIMD over the whole chip
+  int64_t S = 2048 / n_tiles32;                     // 2 waves per SIMD over the whole chip, rounded DOWN: a 513th workgroup
+                                                    // would be a third on its CU (its SIMDs 3 waves deep: +50 % on the critical path)
   const int64_t max_s = (n + 63) / 64;
   if (S > max_s) S = max_s;
   if (S > 64) S = 64;
