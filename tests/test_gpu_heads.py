@@ -111,6 +111,35 @@ def test_grouped_projection_matches_per_task_linear(K, classes, N):
     assert_close(bg.grad, b64.grad.float(), 1e-5, "db")
 
 
+def test_grouped_projection_on_strided_operands():
+    """The persistent forward / input-gradient kernels take row strides from the caller: `a` as a column window of a wider
+    buffer (16-byte aligned rows, as the C-ABI asks), the incoming gradient as a window that starts 4 bytes into rows of an
+    odd stride (the dx movers load single floats: no alignment asked), N not a multiple of the 32-row block."""
+    from analysisgnn_amd.heads import grouped_projection
+    torch.manual_seed(1)
+    classes, K, N = [4, 50, 50, 15, 4, 38, 38, 22, 22, 2, 94, 185, 2, 2, 2, 2, 2, 2, 45, 49, 4], 64, 8237
+    G = len(classes)
+    offs = [0]
+    for c in classes:
+        offs.append(offs[-1] + c)
+    big = torch.randn(N, G * K + 8, device=DEV)
+    a = big[:, 4:4 + G * K].detach().requires_grad_(True)
+    w = (torch.randn(offs[-1], K, device=DEV) * 0.2).requires_grad_(True)
+    b = torch.randn(offs[-1], device=DEV).requires_grad_(True)
+    wide = torch.randn(N, offs[-1] + 3, device=DEV)
+    gout = wide[:, 1:1 + offs[-1]]
+    assert not a.is_contiguous() and not gout.is_contiguous()
+    out = grouped_projection(a, w, b, offs, K)
+    out.backward(gout)
+    a64, w64, b64 = (t.detach().double().requires_grad_(True) for t in (a, w, b))
+    ref = torch.cat([a64[:, g * K:(g + 1) * K] @ w64[offs[g]:offs[g + 1]].t() + b64[offs[g]:offs[g + 1]] for g in range(G)], dim=1)
+    ref.backward(gout.double())
+    assert_close(out, ref.float(), 1e-5, "out")
+    assert_close(a.grad, a64.grad.float(), 1e-5, "da")
+    assert_close(w.grad, w64.grad.float(), 1e-5, "dw")
+    assert_close(b.grad, b64.grad.float(), 1e-5, "db")
+
+
 @pytest.mark.parametrize("wloss", [False, True])
 @pytest.mark.parametrize("extra", [(), (5,), (3,)])      # 335 logit columns (scalar rows) / 340 (float4 backward) / 338 (float2)
 @pytest.mark.parametrize("N,lam,gscale", [(301, 0.1, 1.0), (16000, 0.1, 1.0), (37, 0.5, 3.0)])
