@@ -128,6 +128,7 @@ SIGNATURES = {
     "agnn_wgrad_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "agnn_pack_f32": (C.c_int, [C.c_int32, C.POINTER(PackItem), C.c_void_p]),
+    "agnn_debug_stamp": (C.c_int, [C.c_void_p, C.c_void_p]),
     "agnn_gproj_fwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "agnn_gproj_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
@@ -251,3 +252,21 @@ def make_rels(items: Sequence[dict]):
         arr[i].colscale = it.get("colscale")
         arr[i].ld_src = it["ld_src"]
     return arr
+
+
+# ---- measurement aid: time stamps captured into the step's hipGraph (scripts/step_stamps.py; AGNN_STAMPS=1) ----------------
+STAMPS = {"on": bool(os.environ.get("AGNN_STAMPS")), "names": [], "buf": None,
+          "only": [w for w in os.environ.get("AGNN_STAMPS", "").split(",") if w not in ("", "1", "all")]}
+
+
+def stamp(name: str, device) -> None:
+    """With AGNN_STAMPS set: a one-lane kernel on the current stream stores the 100 MHz device counter under `name` (a call
+    made while a hipGraph is being captured becomes a node of it: every replay refreshes the slot).  Otherwise nothing."""
+    if not STAMPS["on"] or (STAMPS["only"] and not any(w in name for w in STAMPS["only"])):
+        return                          # AGNN_STAMPS=1: all of them; AGNN_STAMPS=a,b: names containing a or b (every stamp is a graph node)
+    if STAMPS["buf"] is None:
+        STAMPS["buf"] = torch.zeros(256, dtype=torch.int64, device=device)
+    if name not in STAMPS["names"]:
+        STAMPS["names"].append(name)
+    k = STAMPS["names"].index(name)
+    check(load().agnn_debug_stamp(STAMPS["buf"].data_ptr() + 8 * k, stream_ptr(torch.device(device))), "agnn_debug_stamp")

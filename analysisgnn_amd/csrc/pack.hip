@@ -88,3 +88,14 @@ extern "C" int agnn_pack_f32(int32_t n_items, const agnn_pack_item_t* items, agn
   }
   return AGNN_OK;
 }
+
+namespace {
+__global__ void k_stamp(unsigned long long* slot) { *slot = wall_clock64(); }
+}  // namespace
+
+extern "C" int agnn_debug_stamp(uint64_t* slot, agnn_stream_t stream_) {
+  using namespace agnn;
+  if (!slot) return fail(AGNN_EINVAL, "debug_stamp: null slot");
+  hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream_), reinterpret_cast<unsigned long long*>(slot));
+  return check_launch("debug_stamp");
+}

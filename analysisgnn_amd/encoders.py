@@ -266,6 +266,27 @@ def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
 LATE_SEQUENCE_BACKWARD = os.environ.get("AGNN_SEQ_LATE", "1") == "1"  # A/B: the sequence branch behind a late-created node (_LateNode)
 
 
+class _Stamp(torch.autograd.Function):
+    """Measurement aid (AGNN_STAMPS=1, _lib.stamp): identity whose forward / backward leave a device time stamp on the stream
+    they run on — where a branch's forward ends and where its backward begins in the replayed hipGraph."""
+
+    @staticmethod
+    def forward(ctx, x, name):
+        ctx.name = name
+        _lib.stamp(name + " fwd", x.device)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is not None:
+            _lib.stamp(ctx.name + " bwd", g.device)
+        return g, None
+
+
+def _stamped(x, name):
+    return _Stamp.apply(x, name) if _lib.STAMPS["on"] and x.requires_grad else x
+
+
 class _FlushPoint(torch.autograd.Function):
     """Identity on the GNN stack's input.  Its backward runs where the stack's backward ends — where the main stream starts
     to idle until the sequence branch's backward arrives — and runs the weight gradients that the backward pass has deferred
@@ -277,7 +298,9 @@ class _FlushPoint(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        _lib.stamp("flush (main) start", g.device)
         flush_deferred()
+        _lib.stamp("flush (main) end", g.device)
         return g
 
 
@@ -303,7 +326,13 @@ class _ForkInput(torch.autograd.Function):
         # and the replay starts feeding the main stream's list when the branch's list is nearly through (3.40 vs 4.00 ms).
         if ctx.side is not None:
             with torch.cuda.stream(ctx.side):
+                if g is not None:
+                    _lib.stamp("sequence branch dX done (side)", g.device)
                 flush_deferred(g.device if g is not None else None)
+                if g is not None:
+                    _lib.stamp("flush (side) end", g.device)
+        if g is not None:
+            _lib.stamp("join (main)", g.device)
         if g_seq is not None:
             if g is None:
                 raise _lib.AgnnError("_ForkInput: the GNN stack produced no input gradient")   # both branches read the input
@@ -418,13 +447,17 @@ class _HybridMixin:
         x = _head(x_note, batch_size)
         if self.use_jk:
             x = self.jk([_head(o, batch_size) for o in outs])
+        x = _stamped(x, "GNN stack")
         if isinstance(z, tuple):
             with torch.cuda.stream(side):                # the node belongs to the side stream, like the branch it stands for
-                z = _LateNode.apply(*z)
+                z = _stamped(_LateNode.apply(*z), "sequence branch")
+        elif side is not None:
+            with torch.cuda.stream(side):
+                z = _stamped(z, "sequence branch")
         if side is not None:
             torch.cuda.current_stream(x.device).wait_stream(side)
             z.record_stream(torch.cuda.current_stream(x.device))
-        return self.cat_proj(torch.cat((x, z), dim=-1))
+        return _stamped(self.cat_proj(torch.cat((x, z), dim=-1)), "cat_proj")
 
 
 class HybridGNN(nn.Module, _HybridMixin):

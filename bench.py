@@ -273,7 +273,13 @@ def main():
     label_mat = I["label_matrix"] if sampler is not None else torch.stack([labels[t] for t in tasks])      # [T, N]
     one = torch.ones((), dtype=torch.float32, device=dev)
 
+    from analysisgnn_amd import _lib as _agnn_lib
+
+    def _lib_stamp(name):                                           # AGNN_STAMPS=1: device time stamps inside the captured step
+        _agnn_lib.stamp(name, dev)
+
     def fwd_bwd():
+        _lib_stamp("step start")
         flat.zero()
         if sampler is not None:
             sampler.sample()                                        # this step's batch: sampled and gathered on the device
@@ -281,8 +287,10 @@ def main():
                          I["batch_size"], I["neighbor_mask_node"], I["neighbor_mask_edge"])      # analysis.py:953-961
         logits, offs, _ = model.forward_clf_fused(x)
         loss, _ = training_loss(logits, offs, label_mat, x, 0.1, 0.1, -1, task_params=clf_loss.weights())   # analysis.py:1034-1036, :1072
+        _lib_stamp("forward + objective issued (main)")
         loss.backward(gradient=one)                                # a resident 1.0: no fill launch for the root gradient
         flat.pack()
+        _lib_stamp("step end (gradients gathered)")
         return loss
 
     def update():
@@ -379,6 +387,14 @@ def main():
         b = sorted(t[1] for t in HOST_T[args.warmup:])
         print(f"[bench] host time in replay calls: step graph median {a[len(a) // 2] * 1e6:.0f} us (max {a[-1] * 1e6:.0f}), "
               f"update graph median {b[len(b) // 2] * 1e6:.0f} us; wall per step {dt / args.steps * 1e6:.0f} us", file=sys.stderr)
+    if _agnn_lib.STAMPS["on"] and _agnn_lib.STAMPS["buf"] is not None and rank == 0:
+        # the LAST replay's stamps (100 MHz device counter), relative to the step's first one
+        v = _agnn_lib.STAMPS["buf"].cpu().tolist()
+        names = _agnn_lib.STAMPS["names"]
+        t_first = min(v[k] for k in range(len(names)) if v[k])
+        print(f"[bench] in-graph time stamps of the last replay (us since '{names[0]}'; wall per step {dt / args.steps * 1e6:.0f} us):", file=sys.stderr)
+        for k in sorted(range(len(names)), key=lambda k: v[k]):
+            print(f"[bench]   {(v[k] - t_first) / 100.0:9.1f}  {names[k]}", file=sys.stderr)
     assert torch.isfinite(loss).item(), "loss diverged"
     from analysisgnn_amd import _lib
     _lib.check_device_status(dev)                      # no CSR build of the run flagged an inconsistent index (outside the timed region)

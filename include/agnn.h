@@ -335,6 +335,11 @@ typedef struct {
 } agnn_pack_item_t;
 int agnn_pack_f32(int32_t n_items, const agnn_pack_item_t* items /* (host) */, agnn_stream_t stream);
 
+/* Measurement aid (scripts/step_stamps.py): one single-lane kernel that stores the constant-rate 100 MHz counter
+ * (s_memrealtime) into *slot when the stream reaches it — a time stamp that can be captured into a hipGraph and read back
+ * after the replay, without a profiler attached.  Not used by the product path. */
+int agnn_debug_stamp(uint64_t* slot /* (device) */, agnn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Note-input assembly (ref: models/analysis.py:574 `torch.cat([x_dict["note"], self.pitch_embedding(pitch_spelling),
  * self.key_embedding(key_signature)], dim=-1)`; tables models/analysis.py:399-400) and the gradient of the tables.
