@@ -79,7 +79,8 @@ def test_model_forward_clf_is_dict_of_views():
                                          (64, [4, 50, 50, 15, 4, 38, 38, 22, 22, 2, 94, 185, 2, 2, 2, 2, 2, 2, 45, 49, 4], 16001),
                                          (64, [3, 400, 17, 16, 5], 130),        # a four-group chunk wider than the LDS logits image
                                          (64, [1] * 32, 65), (64, [7], 5), (64, [40] * 31, 200),
-                                         (64, [5] * 17, 97), (64, [9, 30, 2] * 6, 20011), (64, [100] * 9, 300), (64, [33, 1] * 3, 31)])
+                                         (64, [5] * 17, 97), (64, [9, 30, 2] * 6, 20011), (64, [100] * 9, 300), (64, [33, 1] * 3, 31),
+                                         (64, [6, 17, 40, 3, 30], 70001)])
 def test_grouped_projection_matches_per_task_linear(K, classes, N):
     """agnn_gproj_* against T separate nn.Linear(K, C_t) evaluated in float64 (forward, da, dw, db).  K = 64 takes the
     persistent whole-row forward kernel (32-row blocks, one workgroup per CU, ceil(G / 16) equal chunks of groups through
@@ -88,7 +89,7 @@ def test_grouped_projection_matches_per_task_linear(K, classes, N):
     tile slots per wave), 17 groups (chunks of 9 + 8) and three row blocks per workgroup.  The input gradient takes the
     persistent whole-row kernel when the class total is even (8-byte row loads) and the padded image fits (the other cases
     keep the one-wave-per-tile kernel): 900 classes are eight 128-column pieces per row, [33, 1] * 3 has groups of one step
-    and of three with a padded tail, 31 rows are less than one block."""
+    and of three with a padded tail, 31 rows are less than one block; 70 001 rows are nine row blocks per workgroup."""
     from analysisgnn_amd.heads import grouped_projection
     torch.manual_seed(0)
     G = len(classes)
