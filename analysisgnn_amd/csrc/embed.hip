@@ -12,12 +12,14 @@
 // per-wave partial sums go to slabs that `launch_slab_reduce` (wgrad.hip) adds in a fixed order: bitwise
 // reproducible.  It replaces onehot(idx)^T @ dOut (arange, compare, two copies, split-N GEMM, reduce — per table).
 // Byte-bound work (N x D x 4 B read once), no MFMA on purpose.
+#include <cstdlib>
+
 #include "agnn_common.h"
 
 namespace {
 
 constexpr int kMaxTab = AGNN_EMBED_MAX_TABLES;
-constexpr int kSlices = 8;          // row slices per table row; x 4 waves = 32 slabs
+constexpr int kSlices = 128;        // row slices; x 4 waves = 512 slabs (a wave's rows: 32 at N = 16 000)
 
 struct EmbFwd {
   const float* x;
@@ -94,6 +96,69 @@ __global__ __launch_bounds__(256) void k_embed_bwd(EmbBwd a) {
   }
 }
 
+// The same sums with every index read ONCE: a wave walks its slice of the rows (all tables' columns of a row side by side
+// in the lanes, 256 contiguous bytes per load, eight rows' loads in flight) and adds each value into its own LDS image of
+// all the tables (lane = column: no two lanes share an address; rows in order: bitwise reproducible), then writes the
+// image to its slab.  The kernel above scans the whole index vector once per TABLE ROW and fetches the matching rows one
+// dependent load at a time: 35 - 48 us per launch on the serial tail of the step (profiles/r02_step_stamps.md), this one 30.
+constexpr int kEmbLdsFloats = 4096;     // per wave: v_total * dim floats
+
+template <int NCG>                       // 64-column groups of the tables' columns side by side (host: ceil(n_tab * dim / 64))
+__global__ __launch_bounds__(256) void k_embed_bwd_rows(EmbBwd a) {
+  __shared__ float s_acc[4][kEmbLdsFloats];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* acc = s_acc[wave];
+  const int img = a.v_total * a.dim;
+  for (int e = lane; e < img; e += 64) acc[e] = 0.f;
+  const int part = blockIdx.x * 4 + wave;
+  const int64_t per = (a.n_rows + kSlices * 4 - 1) / (kSlices * 4);
+  const int64_t r0 = part * per;
+  int64_t r1 = r0 + per;
+  if (r1 > a.n_rows) r1 = a.n_rows;
+  const int width = a.n_tab * a.dim;
+  // this lane's columns 64 g + lane: their table, its rows in the image, the column inside the table
+  bool on[NCG];
+  int cc[NCG], vb[NCG], vn[NCG], col[NCG];
+  const int64_t* idx[NCG];
+#pragma unroll
+  for (int g = 0; g < NCG; ++g) {
+    const int c = 64 * g + lane;
+    on[g] = c < width;
+    const int t = on[g] ? c / a.dim : 0;
+    cc[g] = c - t * a.dim;
+    idx[g] = a.idx[t];
+    vb[g] = a.vbase[t];
+    vn[g] = a.vbase[t + 1] - vb[g];
+    col[g] = a.col0 + (on[g] ? c : 0);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  constexpr int RB = NCG <= 2 ? 8 : 4;                   // rows per trip: 2 * NCG * RB loads in flight
+  for (int64_t base = r0; base < r1; base += RB) {
+    float val[RB][NCG];
+    int64_t id[RB][NCG];
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const int64_t r = base + u < r1 ? base + u : r1 - 1;
+#pragma unroll
+      for (int g = 0; g < NCG; ++g) {
+        id[u][g] = idx[g][r];
+        val[u][g] = a.dout[r * a.ld_dout + col[g]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RB; ++u)                           // rows in order; an id outside the table contributes nothing, as above
+#pragma unroll
+      for (int g = 0; g < NCG; ++g)
+        if (on[g] && base + u < r1 && id[u][g] >= 0 && id[u][g] < vn[g]) acc[(vb[g] + static_cast<int>(id[u][g])) * a.dim + cc[g]] += val[u][g];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  float* dst = a.slab + static_cast<int64_t>(part) * a.v_pad * a.dim_pad;
+  for (int e = lane; e < img; e += 64) dst[e] = acc[e];    // (dim_pad == dim: the slab rows are the image rows)
+}
+
 }  // namespace
 
 extern "C" size_t agnn_embed_workspace_bytes(int32_t n_tab, const int32_t* vocab, int32_t dim) {
@@ -150,7 +215,17 @@ extern "C" int agnn_embed_cat_bwd_f32(const float* dout, int64_t ld_dout, int32_
   a.v_total = vt; a.v_pad = vt;
   a.slab = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t{255});
   hipStream_t s = static_cast<hipStream_t>(stream_);
-  hipLaunchKernelGGL(k_embed_bwd, dim3(vt, kSlices), dim3(256), 0, s, a);
-  if (int rc = check_launch("embed_bwd")) return rc;
+  static const bool old_kernel = getenv("AGNN_EMBED_BWD_OLD") != nullptr;      // A/B switch
+  const int ncg = (n_tab * dim + 63) / 64;
+  if (static_cast<int64_t>(vt) * dim <= kEmbLdsFloats && ncg <= 4 && !old_kernel) {
+    if (ncg == 1) hipLaunchKernelGGL(k_embed_bwd_rows<1>, dim3(kSlices), dim3(256), 0, s, a);
+    else if (ncg == 2) hipLaunchKernelGGL(k_embed_bwd_rows<2>, dim3(kSlices), dim3(256), 0, s, a);
+    else if (ncg == 3) hipLaunchKernelGGL(k_embed_bwd_rows<3>, dim3(kSlices), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_embed_bwd_rows<4>, dim3(kSlices), dim3(256), 0, s, a);
+    if (int rc = check_launch("embed_bwd(rows)")) return rc;
+  } else {
+    hipLaunchKernelGGL(k_embed_bwd, dim3(vt, kSlices), dim3(256), 0, s, a);
+    if (int rc = check_launch("embed_bwd")) return rc;
+  }
   return launch_slab_reduce(a.slab, nullptr, kSlices * 4, vt, dim, vt, dim, dtables, dim, nullptr, s);
 }
