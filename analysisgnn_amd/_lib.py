@@ -37,7 +37,7 @@ ROWEND_MAX_ITEMS = 64
 class Sampler(C.Structure):
     _fields_ = [("n_rel", C.c_int32), ("rowptr", C.c_void_p * 8), ("col", C.c_void_p * 8), ("win_start", C.c_void_p),
                 ("n_sub", C.c_int32), ("n_targets", C.c_int32), ("n_hops", C.c_int32), ("fan", C.c_int32 * 4), ("cap", C.c_int32 * 4),
-                ("rng", C.c_void_p), ("node_gid", C.c_void_p), ("edges", C.c_void_p * 8), ("e_cap", C.c_int64), ("status", C.c_void_p)]
+                ("rng", C.c_void_p), ("node_gid", C.c_void_p), ("edges", C.c_void_p * 8), ("e_cap", C.c_int64), ("status", C.c_void_p), ("drops", C.c_void_p)]
 
 
 class ReltItem(C.Structure):

@@ -98,6 +98,8 @@ class DeviceSampler:
             cfg.edges[r] = self.edges[et].data_ptr()
         cfg.e_cap = self.e_cap
         cfg.status = _lib.status_word(dev).data_ptr()
+        self.drops = torch.zeros(1, dtype=torch.int32, device=dev)     # statistic, not an error: see dropped()
+        cfg.drops = self.drops.data_ptr()
         self._cfg = cfg
         B, T = self.n_sub, self.n_targets
         self.batch_size = B * T
@@ -131,6 +133,10 @@ class DeviceSampler:
         self._ring_pos = (self._ring_pos + 1) % len(self._ring)
         buf.numpy()[:] = win_start
         self.win_start.copy_(buf, non_blocking=True)
+
+    def dropped(self) -> int:
+        """Sources cut by the hop capacities since this sampler was created (synchronises; a statistic, not an error)."""
+        return int(self.drops.item())
 
     def sample(self) -> dict:
         """Advance the step counter, sample, gather features and attributes — four launches, graph-capturable."""

@@ -21,7 +21,7 @@ extern "C" int agnn_check_status(const int32_t* status, agnn_stream_t stream_) {
   if (e != hipSuccess) return fail(AGNN_ERUNTIME, "check_status: %s", hipGetErrorString(e));
   if (host != 0)
     return fail(AGNN_ERUNTIME, "device status word = %d: kernels flagged %d events since it was zeroed (agnn_csr_build: an edge position outside "
-                "its row, i.e. counters not clean when the build started; agnn_sample_hops: a sampled source dropped because a hop "
-                "produced more new nodes than its capacity)", host, host);
+                "its row, i.e. counters not clean when the build started; agnn_sample_hops: a subgraph proposed more distinct "
+                "out-of-window sources than the kernel's table holds and the batch is incomplete)", host, host);
   return AGNN_OK;
 }

@@ -24,9 +24,16 @@
 
 namespace {
 
-constexpr int kHash = 1024;       // LDS hash set of the non-window nodes of one subgraph (<= sum of caps, <= 512)
-constexpr int kNewMax = 512;      // candidates of one hop before the cut to cap[h]
+// LDS hash set of EVERY distinct out-of-window source a subgraph's hops propose — the kept ones (<= sum of caps) and the
+// ones the capacity cut dropped, which stay known so that a later hop does not bring them back.  A window of consecutive
+// notes proposes a few dozen such sources; the worst case (n_targets * n_rel * fan distinct ones) does not fit any LDS
+// table, so a full table is an ERROR the kernel reports through `status` (the source is treated as dropped, every probe
+// loop is bounded by kHash), never a hang.
+constexpr int kHash = 4096;
+constexpr int kNewMax = 512;      // list of one hop's candidates; more than that: the cap smallest are found by a search over the table
 constexpr int kEmpty = -1;
+constexpr int kValDropped = -1;   // hval: known, without a batch slot
+constexpr int kValNew = -2;       // hval: proposed in the hop being processed
 
 struct SamplerArgs {
   agnn_sampler_t c;
@@ -63,7 +70,7 @@ __device__ __forceinline__ int select_positions(int deg, int fan, uint32_t dst, 
   return m;
 }
 
-__device__ __forceinline__ uint32_t hslot(int gid) { return (static_cast<uint32_t>(gid) * 2654435761u) >> 22; }   // 10 bits
+__device__ __forceinline__ uint32_t hslot(int gid) { return (static_cast<uint32_t>(gid) * 2654435761u) >> 20; }   // 12 bits
 
 constexpr int kThreads = 1024;    // one workgroup per subgraph: 16 waves walk the (frontier node, relation) items side by side
 
@@ -73,15 +80,15 @@ __global__ __launch_bounds__(kThreads) void k_sample_hops(SamplerArgs A) {
   __shared__ int hval[kHash];
   __shared__ int newl[kNewMax];
   __shared__ int fr_gid[AGNN_SAMPLER_MAX_CAP];
-  __shared__ int n_new, n_drop;
+  __shared__ int n_new, n_drop, n_over, n_le;
   const int s = blockIdx.x, tid = threadIdx.x;
   const int T = c.n_targets;
   const int w = c.win_start[s];
   const uint2 key = make_uint2(static_cast<uint32_t>(c.rng[0]), static_cast<uint32_t>(static_cast<uint64_t>(c.rng[0]) >> 32));
   const uint32_t step = static_cast<uint32_t>(c.rng[1]);
-  for (int i = tid; i < kHash; i += kThreads) { hkey[i] = kEmpty; hval[i] = -1; }
+  for (int i = tid; i < kHash; i += kThreads) { hkey[i] = kEmpty; hval[i] = kValDropped; }
   for (int i = tid; i < T; i += kThreads) c.node_gid[static_cast<int64_t>(s) * T + i] = w + i;
-  if (tid == 0) n_drop = 0;
+  if (tid == 0) { n_drop = 0; n_over = 0; }
   __syncthreads();
 
   int64_t nbase = static_cast<int64_t>(c.n_sub) * T;          // first batch node of this hop's block
@@ -104,21 +111,49 @@ __global__ __launch_bounds__(kThreads) void k_sample_hops(SamplerArgs A) {
         const int src = c.col[r][st + pos[k]];
         if (src >= w && src < w + T) continue;
         uint32_t q = hslot(src);
-        for (int probe = 0; probe < kHash; ++probe, q = (q + 1) & (kHash - 1)) {
+        int probe = 0;
+        for (; probe < kHash; ++probe, q = (q + 1) & (kHash - 1)) {
           const int old = atomicCAS(&hkey[q], kEmpty, src);
           if (old == kEmpty) {                              // first sight of this node
+            hval[q] = kValNew;
             const int idx = atomicAdd(&n_new, 1);
             if (idx < kNewMax) newl[idx] = src;
             break;
           }
           if (old == src) break;
         }
+        if (probe == kHash) atomicAdd(&n_over, 1);          // table full: the source is lost (phase C finds nothing), reported
       }
     }
     __syncthreads();
+    if (n_new > kNewMax) {
+      // More candidates than the list holds (which ones it holds depends on the order of the atomics): take the `cap`
+      // smallest ids out of the table instead.  Binary search for the cap-th smallest id among this hop's entries (ids are
+      // distinct), then list the entries up to it: a pure function of the candidate SET.
+      int lo = 0, hi = 0x7fffffff;                          // invariant: count(id <= hi) >= cap (n_new > kNewMax >= cap)
+      while (lo < hi) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if (tid == 0) n_le = 0;
+        __syncthreads();
+        int mine = 0;
+        for (int i = tid; i < kHash; i += kThreads) mine += (hval[i] == kValNew && hkey[i] <= mid) ? 1 : 0;
+        if (mine) atomicAdd(&n_le, mine);
+        __syncthreads();
+        const int le = n_le;
+        __syncthreads();
+        if (le >= cap) hi = mid; else lo = mid + 1;
+      }
+      for (int i = tid; i < kNewMax; i += kThreads) newl[i] = 0x7fffffff;
+      if (tid == 0) n_le = 0;
+      __syncthreads();
+      for (int i = tid; i < kHash; i += kThreads)
+        if (hval[i] == kValNew && hkey[i] <= lo) newl[atomicAdd(&n_le, 1)] = hkey[i];    // exactly cap entries, sorted below
+      __syncthreads();
+    }
     // ---- B: ascending global id (bitonic sort of the padded list), the first `cap` get this hop's slots
+    const int listed = n_new <= kNewMax ? n_new : cap;
     int P = 2;                                              // sort only as many slots as there are candidates (usually a handful)
-    while (P < n_new && P < kNewMax) P <<= 1;
+    while (P < listed && P < kNewMax) P <<= 1;
     for (int k2 = 2; k2 <= P; k2 <<= 1) {
       for (int j = k2 >> 1; j > 0; j >>= 1) {
         for (int i = tid; i < P; i += kThreads) {
@@ -132,17 +167,21 @@ __global__ __launch_bounds__(kThreads) void k_sample_hops(SamplerArgs A) {
         __syncthreads();
       }
     }
-    const int found = n_new < kNewMax ? n_new : kNewMax;
-    const int kept = found < cap ? found : cap;
+    const int kept = listed < cap ? listed : cap;
     if (tid == 0 && n_new > kept) n_drop += n_new - kept;
     for (int i = tid; i < cap; i += kThreads) {
       const int g = i < kept ? newl[i] : -1;
       c.node_gid[nbase + static_cast<int64_t>(s) * cap + i] = g;
       if (i < kept) {
         uint32_t q = hslot(g);
-        while (hkey[q] != g) q = (q + 1) & (kHash - 1);
+        for (int probe = 0; probe < kHash && hkey[q] != g; ++probe) q = (q + 1) & (kHash - 1);   // g is in the table: it was listed from it
         hval[q] = static_cast<int>(nbase + static_cast<int64_t>(s) * cap + i);
       }
+    }
+    __syncthreads();
+    if (n_new > kept) {                                     // the candidates the cut dropped stay known, without a slot
+      for (int i = tid; i < kHash; i += kThreads)
+        if (hval[i] == kValNew) hval[i] = kValDropped;
     }
     __syncthreads();
     // ---- C: the edges, every (frontier node, relation, k) in its own slot
@@ -166,8 +205,9 @@ __global__ __launch_bounds__(kThreads) void k_sample_hops(SamplerArgs A) {
             src_l = static_cast<int64_t>(s) * T + (src - w);
           } else {
             uint32_t q = hslot(src);
-            while (hkey[q] != src && hkey[q] != kEmpty) q = (q + 1) & (kHash - 1);
-            src_l = hkey[q] == src ? hval[q] : -1;          // -1: dropped by the capacity cut
+            int probe = 0;
+            for (; probe < kHash && hkey[q] != src && hkey[q] != kEmpty; ++probe) q = (q + 1) & (kHash - 1);
+            src_l = (probe < kHash && hkey[q] == src) ? hval[q] : -1;   // -1: dropped by the capacity cut (or lost to a full table)
           }
         }
         e0[k] = src_l;
@@ -184,7 +224,8 @@ __global__ __launch_bounds__(kThreads) void k_sample_hops(SamplerArgs A) {
     Fcap = cap;
     __syncthreads();
   }
-  if (tid == 0 && n_drop > 0 && c.status != nullptr) atomicAdd(c.status, n_drop);
+  if (tid == 0 && n_drop > 0 && c.drops != nullptr) atomicAdd(c.drops, n_drop);        // a statistic: expected on crowded scores
+  if (tid == 0 && n_over > 0 && c.status != nullptr) atomicAdd(c.status, n_over);      // an error: the batch is incomplete
 }
 
 // out[i, :] = gid[i] >= 0 ? src[gid[i], :] : 0   (float rows, H % 4 == 0; one 16-lane group per row)
@@ -243,7 +284,7 @@ extern "C" int agnn_sample_hops(const agnn_sampler_t* cfg, agnn_stream_t stream_
     if (c.cap[h] <= 0 || c.cap[h] > AGNN_SAMPLER_MAX_CAP) return fail(AGNN_EINVAL, "sample_hops: cap[%d]=%d not in [1,%d]", h, c.cap[h], AGNN_SAMPLER_MAX_CAP);
     cap_sum += c.cap[h];
   }
-  if (cap_sum > kHash / 2) return fail(AGNN_EINVAL, "sample_hops: sum of capacities %d > %d", cap_sum, kHash / 2);
+  if (cap_sum > kHash / 4) return fail(AGNN_EINVAL, "sample_hops: sum of capacities %d > %d", cap_sum, kHash / 4);
   if (!c.win_start || !c.rng || !c.node_gid) return fail(AGNN_EINVAL, "sample_hops: null argument");
   if (c.e_cap != agnn_sampler_edge_capacity(cfg)) return fail(AGNN_EINVAL, "sample_hops: e_cap=%lld, expected %lld", (long long)c.e_cap, (long long)agnn_sampler_edge_capacity(cfg));
   for (int r = 0; r < c.n_rel; ++r)

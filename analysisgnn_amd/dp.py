@@ -220,6 +220,21 @@ def defer_weight_grads(flag: bool = True) -> None:
     _set(flag)
 
 
+def fill_missing_grads(module_or_params) -> int:
+    """Give every trainable parameter that took no gradient this step a ZERO gradient; returns how many.  The encoders prune
+    structurally dead branches (hgt._HGTCore: a node type nothing reads; encoders.HeteroConv: a layer that keeps no edge hands
+    zeros itself), where the reference's graph still reaches those parameters through empty index ops and gives zeros.
+    `torch.optim.AdamW` SKIPS a parameter whose grad is None (no weight decay, no moment decay), so a stock optimizer
+    reproduces the reference's update only after this call; FlatGradBuffer.pack + FlatAdamW substitute zeros themselves."""
+    params = module_or_params.parameters() if isinstance(module_or_params, torch.nn.Module) else module_or_params
+    n = 0
+    for p in params:
+        if p.requires_grad and p.grad is None:
+            p.grad = torch.zeros_like(p)
+            n += 1
+    return n
+
+
 def barrier_and_sync() -> None:
     if dist.is_initialized():
         dist.barrier()

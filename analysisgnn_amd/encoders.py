@@ -336,7 +336,14 @@ class _ForkInput(torch.autograd.Function):
         if g_seq is not None:
             if g is None:
                 raise _lib.AgnnError("_ForkInput: the GNN stack produced no input gradient")   # both branches read the input
-            g[:ctx.n] += g_seq                       # in place: the GNN stack's gradient is this node's alone
+            # Out of place: autograd does not promise that `g` has no other holder (a backward that returns its incoming
+            # gradient unchanged hands the same tensor to two consumers).  n is (nearly) all rows, so this moves the same
+            # bytes as the in-place add over n rows would.
+            out = torch.empty_like(g)
+            torch.add(g[:ctx.n], g_seq, out=out[:ctx.n])
+            if ctx.n < g.shape[0]:
+                out[ctx.n:].copy_(g[ctx.n:])
+            g = out
         return g, None, None
 
 
@@ -365,6 +372,10 @@ class _LateNode(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz):
         inner, ctx.inner = ctx.inner, None
+        if inner is None:
+            raise _lib.AgnnError("the sequence branch's private autograd graph was freed by the first backward pass: a second "
+                                 "backward (retain_graph=True, torch.autograd.grad twice) is not supported while "
+                                 "dp.defer_weight_grads is on with encoders.LATE_SEQUENCE_BACKWARD — switch either off")
         if dz is None:
             return None, None
         torch.autograd.backward([inner.z], [dz])
@@ -414,16 +425,16 @@ class _HybridMixin:
             if known is not None and sum(int(v) for v in known) == batch_size:
                 batch_note.agnn_target_lengths = known
         if not (self.overlap_sequence_branch and x_in.is_cuda):
-            return self.hybrid_forward(_head(x_in, batch_size), batch_note), None
+            return self.hybrid_forward(_head(x_in, batch_size), batch_note), None, None
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev)
-        self._gnn_note = None
+        gnn_note = None
         x_seq = None
         if torch.is_grad_enabled() and x_in.requires_grad and deferring(x_in):
             # deferred weight gradients: the two branches hang off one node whose backward is their join (_ForkInput), and the
             # GNN stack's input passes through the main stream's flush point (_FlushPoint)
             x_gnn, x_seq = _ForkInput.apply(x_in, batch_size, side)
-            self._gnn_note = _FlushPoint.apply(x_gnn)
+            gnn_note = _FlushPoint.apply(x_gnn)
         side.wait_stream(main)
 
         set_home_stream(main)
@@ -432,16 +443,17 @@ class _HybridMixin:
                 x_leaf = x_seq.detach().requires_grad_(True)
                 inner = self.hybrid_forward(x_leaf, batch_note)
             if inner.requires_grad:
-                return (x_seq, _Inner(inner, x_leaf)), side        # the node is created in `_finish`, after the GNN stack
-            return inner, side
+                return (x_seq, _Inner(inner, x_leaf)), side, gnn_note   # the node is created in `_finish`, after the GNN stack
+            return inner, side, gnn_note
         with torch.cuda.stream(side):
             z = self.hybrid_forward(x_seq if x_seq is not None else _head(x_in, batch_size), batch_note)
-        return z, side
+        return z, side, gnn_note
 
-    def _gnn_input(self, x_dict, side):
-        """The GNN stack's input: the dict itself, or (deferred weight gradients) the note matrix behind the flush point."""
-        note, self._gnn_note = getattr(self, "_gnn_note", None), None
-        return x_dict if note is None else {**x_dict, "note": note}
+    @staticmethod
+    def _gnn_input(x_dict, gnn_note):
+        """The GNN stack's input: the dict itself, or (deferred weight gradients) the note matrix behind the flush point.
+        (`gnn_note` travels through the caller's frame, not through the module: forward stays re-entrant.)"""
+        return x_dict if gnn_note is None else {**x_dict, "note": gnn_note}
 
     def _finish(self, x_note, outs, z, side, batch_size):
         x = _head(x_note, batch_size)
@@ -484,8 +496,8 @@ class HybridGNN(nn.Module, _HybridMixin):
             batch_size = int(x_dict["note"].shape[0])
         plan = TrimPlan(self.num_layers, x_dict, edge_index_dict, neighbor_mask_node, neighbor_mask_edge)
         outs: list = []
-        z, side = self._start_branch(x_dict["note"], batch_dict, batch_size)
-        h = self.gnn(self._gnn_input(x_dict, side), edge_index_dict, plan, outs)
+        z, side, gnn_note = self._start_branch(x_dict["note"], batch_dict, batch_size)
+        h = self.gnn(self._gnn_input(x_dict, gnn_note), edge_index_dict, plan, outs)
         out = self._finish(h["note"], outs, z, side, batch_size)
         return (out, edge_index_dict) if return_edge_index else out
 

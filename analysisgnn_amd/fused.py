@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .linear import _steals, defer, deferring
+from .linear import all_steal, defer, deferring, leaf_refs
 
 PRE_RELU, POST_RELU = 1, 2
 ENABLED = True
@@ -39,13 +39,12 @@ def _al16(t: torch.Tensor) -> torch.Tensor:
 
 class _NormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, p, flags, call_id, seg=0, defer_ok=False):
+    def forward(ctx, x, gamma, beta, eps, p, flags, call_id, seg=0, defer_ok=False, steal_refs=None):
         """x [n, H]; gamma / beta [H]; statistics over segments of `seg` floats (0 = the whole row).  `defer_ok`: gamma / beta
         are leaves, or reach their leaves through views only (their gradients may be produced late: linear.defer_weight_grads)."""
         dev = _lib.require_gpu(x, gamma, beta)
         ctx.defer_ok = bool(defer_ok) or (gamma.is_leaf and beta.is_leaf)
-        ctx.gamma_ref = gamma if gamma.is_leaf else None
-        ctx.beta_ref = beta if beta.is_leaf else None
+        ctx.steal_refs = leaf_refs(gamma, beta) if steal_refs is None else tuple(steal_refs)   # reshaped operands: the caller names the leaves
         lib = _lib.load()
         x = x if (x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else x.contiguous()
         n, H = x.shape
@@ -81,7 +80,7 @@ class _NormAct(torch.autograd.Function):
         rng = used[0] if p > 0 else None                     # the forward call's own (seed, step), not the live counter
         # dgamma / dbeta only feed the optimizer: with deferred weight gradients (linear.defer_weight_grads) their column-sum
         # launch leaves the chain too (the closure works on aliases: see linear._LinearFn.backward)
-        later = ctx.defer_ok and deferring(dy) and _steals(ctx.gamma_ref) and _steals(ctx.beta_ref)
+        later = ctx.defer_ok and deferring(dy) and all_steal(ctx.steal_refs)
         _lib.check(lib.agnn_norm_act_bwd_f32(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), seg, n, H, eps, p, flags,
                                              _lib.ptr(rng), call_id, dy.data_ptr(), dy.stride(0), mean.data_ptr(), rstd.data_ptr(),
                                              dx.data_ptr(), dx.stride(0), None if later else dgamma.data_ptr(),
@@ -91,7 +90,7 @@ class _NormAct(torch.autograd.Function):
             dg_k, db_k = dgamma.detach(), dbeta.detach()
             defer(lambda: _lib.check(lib.agnn_norm_act_colsum_f32(ws.data_ptr(), nws, n, H, dg_k.data_ptr(), db_k.data_ptr(),
                                                                   _lib.stream_ptr(dev)), "agnn_norm_act_colsum_f32"), dev)
-        return dx, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 def norm_act(x: torch.Tensor, ln: nn.LayerNorm, pre_relu: bool = False, post_relu: bool = False, p: float = 0.0,
@@ -123,7 +122,7 @@ def grouped_norm_act(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, e
         return F.layer_norm(y, (H,), None, None, eps) * gamma + beta
     view_only = all(t.is_leaf or getattr(t, "_agnn_wgrad_deferrable", False) for t in (gamma, beta))
     y = _NormAct.apply(x.reshape(N, W), gamma.reshape(W), beta.reshape(W), eps, 0.0, PRE_RELU if pre_relu else 0,
-                       next(_CALL_IDS) & 0xFFFFFFFF, H, view_only)
+                       next(_CALL_IDS) & 0xFFFFFFFF, H, view_only, leaf_refs(gamma, beta))
     return y.view(N, G, H)
 
 

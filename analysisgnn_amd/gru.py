@@ -11,7 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .linear import defer, defer_home, deferring, mark_wgrad_async, weight_grad, wgrad_stream
+from .linear import all_steal, defer, defer_home, deferring, leaf_refs, mark_wgrad_async, weight_grad, wgrad_stream
 
 KERNEL_HIDDEN = 128
 
@@ -46,6 +46,7 @@ class _GRULayer(torch.autograd.Function):
         ctx.save_for_backward(x2, w_ih, w_hh_c, y, saved, *([drop_scale] if drop_scale is not None else []))
         ctx.dims = (B, T, I, Hh)
         ctx.wg_async = all(getattr(t, "_agnn_wgrad_async", False) or t.is_leaf for t in (w_ih, w_hh, b_ih, b_hh))
+        ctx.steal_refs = leaf_refs(w_ih, w_hh, b_ih, b_hh)
         return out
 
     @staticmethod
@@ -84,17 +85,21 @@ class _GRULayer(torch.autograd.Function):
             for d in range(2):
                 weight_grad(dgh2[:, d * 3 * Hh:(d + 1) * 3 * Hh], hp2[:, d * Hh:(d + 1) * Hh], True, dw_out=dw_hh[d], db_out=db_hh[d])
 
+        # off the chain only while every parameter behind the stacked operands takes its gradient over without a kernel
+        # (no .grad yet, no hook): otherwise AccumulateGrad adds on this stream at once and must find the values there
+        off_chain = ctx.wg_async and all_steal(ctx.steal_refs)
+
         def forked():
-            with wgrad_stream(dev, dgi, dgh, y, x2, hp, dw_ih, db_ih, dw_hh, db_hh, active=ctx.wg_async, kind="sequence"):
+            with wgrad_stream(dev, dgi, dgh, y, x2, hp, dw_ih, db_ih, dw_hh, db_hh, active=off_chain, kind="sequence"):
                 weight_grads()
         # The layer whose backward runs last (layer 0) ends the branch: with deferred weight gradients its fork is issued by
         # the branch's join (encoders._ForkInput), AFTER the join's own kernel — the join is then the first-captured dependent
         # of this layer's dX GEMM and is not held back by the replayed graph (profiles/r02_step_timeline.md).
         # Any other layer, with deferred weight gradients on a branch stream: no fork either (a fork inside the chain makes the
         # chain's own continuation a later-captured dependent) — the work goes to the main chain's flush, behind an event.
-        if ctx.last_in_backward and ctx.wg_async and deferring(dy):
+        if ctx.last_in_backward and off_chain and deferring(dy):
             defer(forked, dev)
-        elif not (ctx.wg_async and deferring(dy) and defer_home(weight_grads, dev)):
+        elif not (off_chain and deferring(dy) and defer_home(weight_grads, dev)):
             forked()
         return dx, dw_ih.view(2, 3 * Hh, I), dw_hh, db_ih.view(2, 3 * Hh), db_hh, None, None
 
@@ -181,6 +186,6 @@ def _stack_gru_params(rnn: nn.GRU):
         outs = tuple(torch.stack((flat[i], flat[i + 1])) for i in range(0, len(flat), 2))
         leaves = all(t.is_leaf for t in flat)
     if leaves:
-        for o in outs:
-            mark_wgrad_async(o)
+        for i, o in enumerate(outs):
+            mark_wgrad_async(o, leaves=flat[2 * i:2 * i + 2])
     return outs

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .fused import grouped_norm_act
-from .linear import defer, deferring, linear, mark_wgrad_async, wgrad_stream
+from .linear import all_steal, defer, deferring, leaf_refs, linear, mark_wgrad_async, wgrad_stream
 from .params import cat_rows, stack_rows
 
 
@@ -32,24 +32,32 @@ def fused_head_logits(clf_dict: nn.ModuleDict, x: torch.Tensor, tasks: Sequence[
     h2 = mods[0][0].out_features
     # cat / stack of leaf parameters: their backward is narrow / unbind (views), so these gradients may arrive late;
     # the cats themselves are views when the parameters are adjacent in memory (dp.plan_parameters), launches otherwise
-    W1 = mark_wgrad_async(cat_rows([m[0].weight for m in mods]), deferrable=True)          # [T*h2, o]; the cat's backward only takes views
-    b1 = mark_wgrad_async(cat_rows([m[0].bias for m in mods]), deferrable=True)
+    W1 = _cat_params([m[0].weight for m in mods])                         # [T*h2, o]; the cat's backward only takes views
+    b1 = _cat_params([m[0].bias for m in mods])
     a = linear(x, W1, b1)                                                 # [N, T*h2]
-    gamma = mark_wgrad_async(stack_rows([m[2].weight for m in mods]), deferrable=True)      # [T, h2]; backward = views
-    beta = mark_wgrad_async(stack_rows([m[2].bias for m in mods]), deferrable=True)
+    gamma = _cat_params([m[2].weight for m in mods], stack=True)          # [T, h2]; backward = views
+    beta = _cat_params([m[2].bias for m in mods], stack=True)
     a = grouped_norm_act(a.view(-1, T, h2), gamma, beta, mods[0][2].eps, pre_relu=True)   # ReLU + per-task LayerNorm, one launch
     offs = [0]
     for m in mods:
         offs.append(offs[-1] + m[3].out_features)
-    b2 = cat_rows([m[3].bias for m in mods])
+    b2 = _cat_params([m[3].bias for m in mods])
     a = a.reshape(-1, T * h2)
     if a.is_cuda and h2 in GPROJ_K and T <= _lib.MAX_SEG and GPROJ_ENABLED:
-        W2 = mark_wgrad_async(cat_rows([m[3].weight for m in mods]), deferrable=True)           # [sum C, h2]
-        logits = grouped_projection(a, W2, mark_wgrad_async(b2, deferrable=True), offs, h2)
+        W2 = _cat_params([m[3].weight for m in mods])                     # [sum C, h2]
+        logits = grouped_projection(a, W2, b2, offs, h2)
     else:                                                                 # widths the kernel is not built for
         W2 = torch.block_diag(*[m[3].weight for m in mods])               # [sum C, T*h2]
         logits = linear(a, W2, b2)
     return logits, offs
+
+
+def _cat_params(ps, stack: bool = False) -> torch.Tensor:
+    """cat / stack of LEAF parameters as one operand whose gradient may arrive late (linear.mark_wgrad_async): the
+    backward of either only hands out views, and the consumers check the leaves' `.grad` state before they defer."""
+    ps = list(ps)
+    t = stack_rows(ps) if stack else cat_rows(ps)
+    return mark_wgrad_async(t, deferrable=True, leaves=ps) if all(p.is_leaf for p in ps) else t
 
 
 GPROJ_K = (32, 64, 128)
@@ -70,6 +78,7 @@ class _GroupedProj(torch.autograd.Function):
         dev = _lib.require_gpu(a, w, offs_t)
         ctx._wg_async_in = all(t is None or t.is_leaf or getattr(t, "_agnn_wgrad_async", False) for t in (w, b))
         ctx._wg_defer_in = all(t is None or t.is_leaf or getattr(t, "_agnn_wgrad_deferrable", False) for t in (w, b))
+        ctx.steal_refs = leaf_refs(w, b)
         a = _lib.f32c(a)
         w = _lib.f32c(w)
         if w.data_ptr() % 16:
@@ -110,10 +119,11 @@ class _GroupedProj(torch.autograd.Function):
                 _lib.check(lib.agnn_gproj_bwd_f32(dout.data_ptr(), dout.stride(0), a.data_ptr(), a.stride(0), w.data_ptr(),
                                                   offs_t.data_ptr(), G, K, tiles, sum_c, N, None, 0, dw_k.data_ptr(), _lib.ptr(db_k),
                                                   ws.data_ptr(), nws, _lib.stream_ptr(dev)), "agnn_gproj_bwd_f32")
-            if ctx.wg_async and ctx.wg_defer and deferring(dout):
+            off_chain = ctx.wg_async and all_steal(ctx.steal_refs)      # else: AccumulateGrad adds on THIS stream, right now
+            if off_chain and ctx.wg_defer and deferring(dout):
                 defer(weight_grads, dev)
             else:
-                with wgrad_stream(dev, dout, a, dw_k, db_k, active=ctx.wg_async):
+                with wgrad_stream(dev, dout, a, dw_k, db_k, active=off_chain):
                     weight_grads()
         da = None
         if ctx.needs_input_grad[0]:
@@ -228,8 +238,8 @@ def fused_logit_fusion(proj_layers: nn.ModuleDict, transformer: nn.Module, fusio
     Wp = torch.cat([m[0].weight.t() for m in pm], dim=0)                                 # [sum C, K]
     bp = cat_rows([m[0].bias for m in pm])                                                # [T*K]
     a = grouped_in_projection(logits, Wp, offs, K) + bp
-    gamma = mark_wgrad_async(stack_rows([m[2].weight for m in pm]), deferrable=True)
-    beta = mark_wgrad_async(stack_rows([m[2].bias for m in pm]), deferrable=True)
+    gamma = _cat_params([m[2].weight for m in pm], stack=True)
+    beta = _cat_params([m[2].bias for m in pm], stack=True)
     a = grouped_norm_act(a.view(N, T, K), gamma, beta, pm[0][2].eps, pre_relu=True)       # [N, T, K]
     enh = transformer(a)                                                                  # [N, T, K]
     Wf = cat_rows([fusion_layers[t].weight for t in tasks])                               # [sum C, K]

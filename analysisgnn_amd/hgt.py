@@ -516,6 +516,12 @@ class _HGTCore(torch.autograd.Function):
             dp_all = torch.zeros(p_shape, dtype=torch.float32, device=dev)
             if dps_rows:
                 dp_all.index_copy_(0, _index_tensor(tuple(dps_ids), dev), torch.cat(dps_rows, dim=0) * (1.0 / math.sqrt(D)))
+        if gwk is None:      # no live source type this step: still parameters of the step — zero gradients, as the SAGE path hands out
+            gwk = torch.zeros(wk_shape, dtype=torch.float32, device=dev)
+            gwv = torch.zeros(wv_shape, dtype=torch.float32, device=dev)
+        # A structurally dead node type (no live outgoing relation, its own output unused) gets None: autograd prunes its
+        # whole upstream.  PyG's HGTConv routes those parameters through empty index ops and they receive ZERO gradients;
+        # dp.FlatGradBuffer.pack substitutes zeros, a stock torch optimizer needs dp.fill_missing_grads(model) first.
         return (None, gwk, gwv, dp_all, *[None if t in dead else dkqv[t] for t in plan.types])
 
 
@@ -685,8 +691,8 @@ class HybridHGT(nn.Module, _HybridMixin):
             batch_size = int(x_dict["note"].shape[0])
         plan = TrimPlan(self.num_layers, x_dict, edge_index_dict, neighbor_mask_node, neighbor_mask_edge)
         outs: list = []
-        z, side = self._start_branch(x_dict["note"], batch_dict, batch_size)
-        h = self.gnn(self._gnn_input(x_dict, side), edge_index_dict, plan, outs)
+        z, side, gnn_note = self._start_branch(x_dict["note"], batch_dict, batch_size)
+        h = self.gnn(self._gnn_input(x_dict, gnn_note), edge_index_dict, plan, outs)
         out = self._finish(h["note"], outs, z, side, batch_size)
         return (out, edge_index_dict) if return_edge_index else out
 

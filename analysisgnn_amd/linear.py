@@ -39,12 +39,17 @@ def wgrad_overlap_enabled() -> bool:
     return _WG["enabled"]
 
 
-def mark_wgrad_async(t: torch.Tensor, deferrable: bool = False) -> torch.Tensor:
+def mark_wgrad_async(t: torch.Tensor, deferrable: bool = False, leaves=()) -> torch.Tensor:
     """Declare that the gradient of this (non-leaf) operand is consumed without kernels on the launching stream.
     `deferrable`: it may also be produced LATER than the backward pass reaches its consumer (defer_weight_grads) — true when
-    the consumer only takes views of it, or defers its own kernels behind it."""
+    the consumer only takes views of it, or defers its own kernels behind it.
+    `leaves`: the leaf parameters that (views of) this operand's gradient end up in.  "Without kernels" only holds while
+    every one of them has no `.grad` yet and no hook (`_steals`): with gradient accumulation, `zero_grad(set_to_none=False)`
+    or `FlatGradBuffer(views=True)` AccumulateGrad ADDS on the main stream at once — before a deferred closure or the
+    weight-gradient stream has produced the addend.  The consumers check the leaves at backward time (`all_steal`)."""
     t._agnn_wgrad_async = True
     t._agnn_wgrad_deferrable = bool(deferrable)
+    t._agnn_leaves = tuple(leaves)
     return t
 
 
@@ -59,10 +64,31 @@ def _async_ok(t: Optional[torch.Tensor]) -> bool:
 def _steals(p: Optional[torch.Tensor]) -> bool:
     """At backward time: will autograd take this operand's gradient WITHOUT launching a kernel on the node's (main)
     stream?  A leaf's AccumulateGrad steals a fresh contiguous tensor only when .grad is None and nothing hooks it;
-    otherwise it adds / clones on the main stream, which knows nothing about the weight-gradient stream."""
-    if p is None or not p.is_leaf:
-        return True                     # non-leaf operands were vetted by mark_wgrad_async
+    otherwise it adds / clones on the main stream, which knows nothing about the weight-gradient stream.  A non-leaf
+    operand (a cat / stack / pack of parameters, `mark_wgrad_async`) is as good as the leaves behind it."""
+    if p is None:
+        return True
+    if not p.is_leaf:
+        return all(_steals(q) for q in getattr(p, "_agnn_leaves", ()))
     return p.grad is None and not p._backward_hooks and not getattr(p, "_post_accumulate_grad_hooks", None)
+
+
+def leaf_refs(*ts) -> tuple:
+    """Collected in an op's FORWARD (where the operands still are the caller's Python objects): the leaf parameters whose
+    AccumulateGrad nodes will receive (views of) these operands' gradients."""
+    out = []
+    for t in ts:
+        if t is None:
+            continue
+        out.extend((t,) if t.is_leaf else getattr(t, "_agnn_leaves", ()))
+    return tuple(out)
+
+
+def all_steal(refs) -> bool:
+    """Checked in an op's BACKWARD, right before it decides to produce a gradient late or on another stream.  (A parameter
+    used TWICE in one graph cannot be seen from here — autograd's input buffer then adds the two gradients on the main
+    stream; such models must not enable the overlap / deferral.)"""
+    return all(_steals(p) for p in refs)
 
 
 class wgrad_stream:
@@ -249,7 +275,7 @@ class _LinearFn(torch.autograd.Function):
         ctx.has_bias = b is not None
         ctx.wg_async = _async_ok(w) and _async_ok(b)
         ctx.wg_defer = _deferrable(w) and _deferrable(b)
-        ctx.b_ref = b if (b is not None and b.is_leaf) else None
+        ctx.steal_refs = leaf_refs(w, b)
         ctx.set_materialize_grads(False)          # an undefined output gradient (a structurally dead branch) stays undefined upstream
         if acc is not None:                       # y = acc + x W^T (+ b): the GEMM's beta = 1 epilogue, no separate add
             y = torch.addmm(acc, x, w.t())
@@ -264,7 +290,7 @@ class _LinearFn(torch.autograd.Function):
         dw = db = None
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
-        steals = ctx.wg_async and _steals(w) and _steals(ctx.b_ref)     # gradients taken over without a kernel on this stream
+        steals = ctx.wg_async and all_steal(ctx.steal_refs)     # gradients taken over without a kernel on this stream
         if want_w and steals and ctx.wg_defer and x.shape[1] % 2 == 0 and deferring(dy):
             # only dX stays here.  The closure fills aliases: a second reference to `dw` itself would make AccumulateGrad
             # CLONE it (now, before it is computed) instead of taking it over.

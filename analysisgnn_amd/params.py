@@ -12,7 +12,7 @@ from typing import List, Sequence, Tuple
 import torch
 
 from . import _lib
-from .linear import defer, deferring, mark_wgrad_async, wgrad_stream
+from .linear import all_steal, defer, deferring, mark_wgrad_async, wgrad_stream
 
 
 def pack(items: Sequence[Tuple[torch.Tensor, Sequence[torch.Tensor]]], device) -> None:
@@ -56,6 +56,7 @@ class _SageOperands(torch.autograd.Function):
         ctx.R = R
         ctx.shape = (out_f, in_f)
         ctx.leaves = all(t.is_leaf for t in params)
+        ctx.param_refs = tuple(params)
         return W_l, b, W_r
 
     @staticmethod
@@ -76,10 +77,13 @@ class _SageOperands(torch.autograd.Function):
             pack(items, dev)
         # the incoming gradients may be deferred (linear.defer_weight_grads: they do not exist yet — fan them out behind
         # them) or produced on the weight-gradient stream (fan them out there as well)
-        if ctx.leaves and deferring(dW_l):
+        # ... and only while the parameters take these gradients over without a kernel (linear.all_steal); the producers of
+        # dW_l / db / dW_r looked at the same parameters, so both sides take the same decision
+        off_chain = ctx.leaves and all_steal(ctx.param_refs)
+        if off_chain and deferring(dW_l):
             defer(fan_out, dev)
         else:
-            with wgrad_stream(dev, dW_l, db, dW_r, active=ctx.leaves):
+            with wgrad_stream(dev, dW_l, db, dW_r, active=off_chain):
                 fan_out()
         # unbind: one contiguous tensor per parameter (distinct memory, so each .grad can be taken over as is)
         return (None, *G_l.unbind(0), *G_b.unbind(0), *G_r.unbind(0))
@@ -105,6 +109,7 @@ class _SageOperandsCat(torch.autograd.Function):
         ctx.R, ctx.nl = R, nl
         ctx.shape = (out_f, in_f)
         ctx.leaves = all(t.is_leaf for t in params)
+        ctx.param_refs = tuple(params)
         return W, b
 
     @staticmethod
@@ -127,10 +132,11 @@ class _SageOperandsCat(torch.autograd.Function):
                 items.append((G_b[r].view(1, -1), [db_.view(1, -1)]))
                 items.append((G_r[r], [dW_[:, nl * in_f:]]))
             pack(items, dev)
-        if ctx.leaves and deferring(dW):     # the incoming gradients are deferred too: fan them out behind them (see above)
+        off_chain = ctx.leaves and all_steal(ctx.param_refs)
+        if off_chain and deferring(dW):      # the incoming gradients are deferred too: fan them out behind them (see above)
             defer(fan_out, dev)
         else:
-            with wgrad_stream(dev, dW, db, active=ctx.leaves):
+            with wgrad_stream(dev, dW, db, active=off_chain):
                 fan_out()
         return (None, None, *G_l.unbind(0), *G_b.unbind(0), *G_r.unbind(0))
 
@@ -146,7 +152,7 @@ def sage_operands_cat(w_l: List[torch.Tensor], b_l: List[torch.Tensor], w_r: Lis
     ops_ = _SageOperandsCat.apply(R, with_l, *w_l, *b_l, *w_r)
     if all(t.is_leaf for t in (*w_l, *b_l, *w_r)):
         for t in ops_:
-            mark_wgrad_async(t, deferrable=True)        # the fan-out defers itself behind a deferred gradient
+            mark_wgrad_async(t, deferrable=True, leaves=(*w_l, *b_l, *w_r))   # the fan-out defers itself behind a deferred gradient
     return ops_
 
 
@@ -159,7 +165,7 @@ def sage_operands(w_l: List[torch.Tensor], b_l: List[torch.Tensor], w_r: List[to
     ops_ = _SageOperands.apply(R, *w_l, *b_l, *w_r)
     if all(t.is_leaf for t in (*w_l, *b_l, *w_r)):
         for t in ops_:
-            mark_wgrad_async(t, deferrable=True)
+            mark_wgrad_async(t, deferrable=True, leaves=(*w_l, *b_l, *w_r))
     return ops_
 
 

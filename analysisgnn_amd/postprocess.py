@@ -159,12 +159,16 @@ def checkpoint_state_dict(ckpt: Mapping, prefix: str = "model.") -> Tuple[Dict[s
     return model, rest
 
 
-def load_reference_checkpoint(model: torch.nn.Module, path_or_ckpt, strict: bool = False, clf_loss: Optional[torch.nn.Module] = None):
+def load_reference_checkpoint(model: torch.nn.Module, path_or_ckpt, strict: bool = False, clf_loss: Optional[torch.nn.Module] = None,
+                              allow_encoder_mismatch: bool = False):
     """Load a reference checkpoint into `model` (a `TorchAnalysisGNN` of this package).  Files are read with
     `torch.load(..., weights_only=True)` — nothing from the file is executed; a checkpoint the safe loader refuses
     (Lightning may pickle arbitrary hyper-parameter objects) raises and must be re-saved as a plain state_dict by the
     reference.  Returns (missing_keys, unexpected_keys, hyper_parameters) like `load_state_dict`; `strict=True` raises when
-    either list is non-empty.  `clf_loss` (heads.MultiTaskLoss) receives `clf_loss.params` when given."""
+    either list is non-empty.  `clf_loss` (heads.MultiTaskLoss) receives `clf_loss.params` when given.
+    The encoder's parameter names follow PyG / the build spec of DESIGN §5 — graphmuse's own names cannot be checked offline
+    (parity unpinned) — so ANY missing or unexpected `encoder.*` key raises even with `strict=False`: a silently
+    half-initialised encoder would predict garbage.  `allow_encoder_mismatch=True` opts out (the lists are still returned)."""
     if isinstance(path_or_ckpt, (str, bytes)) or hasattr(path_or_ckpt, "__fspath__"):
         ckpt = torch.load(path_or_ckpt, map_location="cpu", weights_only=True)
     else:
@@ -176,6 +180,10 @@ def load_reference_checkpoint(model: torch.nn.Module, path_or_ckpt, strict: bool
     bad_shape = [k for k in sd if k in own and tuple(sd[k].shape) != tuple(own[k].shape)]
     if bad_shape:
         raise _lib.AgnnError(f"checkpoint tensors with another shape than the model's: {bad_shape[:5]} ...")
+    enc = [k for k in (*missing, *unexpected) if k.startswith("encoder.")]
+    if enc and not allow_encoder_mismatch:
+        raise _lib.AgnnError(f"checkpoint and model disagree on {len(enc)} encoder tensors (e.g. {enc[:4]}): the encoder would "
+                             "keep its random initialisation there; map the names first, or pass allow_encoder_mismatch=True")
     if strict and (missing or unexpected):
         raise _lib.AgnnError(f"checkpoint does not match: missing {missing[:5]} ..., unexpected {unexpected[:5]} ...")
     model.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)

@@ -444,7 +444,11 @@ int agnn_train_loss_bwd_f32(const float* dlogits, int64_t ld, const int32_t* seg
  * rowptr / col: CSR by DESTINATION of every relation over all notes of all scores (int32).  All in-neighbours are taken
  * when there are at most fan[h]; otherwise fan[h] of them without replacement (selection sampling on Philox-4x32-10 keyed
  * by rng = (seed, step) and (destination, relation, hop)).  Hop h+1 expands only the nodes hop h added (PyG semantics).
- * `status` (optional, as in agnn_csr_build) counts sources dropped because a hop produced more than cap[h] new nodes.
+ * `drops` (optional device int32[1], caller-owned, only ever incremented) counts sources dropped because a hop proposed
+ * more than cap[h] new nodes — a STATISTIC, expected on crowded scores: the cap[h] smallest global ids are kept, whatever
+ * their number, and a dropped source stays dropped in later hops.  `status` (optional, the agnn_csr_build word) is bumped
+ * only by an ERROR: a subgraph proposed more distinct out-of-window sources than the kernel's table holds (4096); the
+ * sources that found no place are left out of the batch and agnn_check_status reports it.
  * agnn_gather_rows_f32 / agnn_gather_i64 fetch the batch's feature rows / integer attributes by node_gid (0 / `fill` for
  * padding slots).
  * ------------------------------------------------------------------------------------------ */
@@ -464,7 +468,8 @@ typedef struct {
   int32_t* node_gid;                             /* (device) out [agnn_sampler_num_nodes] */
   int64_t* edges[AGNN_SAMPLER_MAX_REL];          /* (device) out, per relation int64 [2, e_cap] */
   int64_t e_cap;                                 /* = agnn_sampler_edge_capacity */
-  int32_t* status;                               /* (device) int32[1] or NULL */
+  int32_t* status;                               /* (device) int32[1] or NULL: errors (agnn_check_status) */
+  int32_t* drops;                                /* (device) int32[1] or NULL: sources cut by cap[h] (statistic) */
 } agnn_sampler_t;
 int64_t agnn_sampler_num_nodes(const agnn_sampler_t* cfg /* (host) */);
 int64_t agnn_sampler_edge_capacity(const agnn_sampler_t* cfg /* (host) */);

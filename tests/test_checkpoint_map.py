@@ -58,7 +58,11 @@ def test_partial_checkpoint_reports_missing_and_unexpected():
     src, dst = _model(1), _model(2)
     sd = {f"model.{k}": v for k, v in src.state_dict().items() if not k.startswith("encoder.")}
     sd["model.encoder.some_graphmuse_name.weight"] = torch.zeros(3)
-    missing, unexpected, _ = load_reference_checkpoint(dst, {"state_dict": sd})
+    import pytest
+    from analysisgnn_amd._lib import AgnnError
+    with pytest.raises(AgnnError, match="encoder"):             # a half-initialised encoder is never silent
+        load_reference_checkpoint(_model(2), {"state_dict": sd})
+    missing, unexpected, _ = load_reference_checkpoint(dst, {"state_dict": sd}, allow_encoder_mismatch=True)
     assert unexpected == ["encoder.some_graphmuse_name.weight"]
     assert missing and all(k.startswith("encoder.") for k in missing)
     assert torch.equal(dst.state_dict()["project_enc.9.weight"], src.state_dict()["project_enc.9.weight"])

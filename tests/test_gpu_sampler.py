@@ -50,7 +50,9 @@ def test_sampler_matches_oracle_bit_for_bit(fan, cap, T):
     _lib.check_device_status(DEV)                                   # no capacity overflow at these capacities
 
 
-def test_capacity_overflow_is_reported():
+def test_capacity_cut_is_a_statistic_not_an_error():
+    """Sources cut by cap[h] are counted in the sampler's own `drops` word; the device status word (index corruption,
+    agnn_check_status) stays clean, so one crowded batch does not fail every later check of the process."""
     from analysisgnn_amd import _lib
     from analysisgnn_amd.batching import DeviceSampler
     store, _ = _store()
@@ -60,10 +62,74 @@ def test_capacity_overflow_is_reported():
     smp.set_windows(np.array([300, 1200], dtype=np.int32))
     smp.sample()
     torch.cuda.synchronize()
+    assert smp.dropped() > 0
+    assert int(word.item()) == before
+    _lib.check_device_status(DEV)
+
+
+def _crowded_store(n_targets, n_rel, fan):
+    """One score whose first `n_targets` notes each have `fan` in-neighbours per relation, ALL distinct and all outside
+    the window [0, n_targets): n_targets * n_rel * fan distinct candidates in a single subgraph."""
+    from analysisgnn_amd.batching import ScoreStore
+    from analysisgnn_amd.synth import ScoreGraph
+    n = n_targets * (1 + n_rel * fan) + 8
+    ei = {}
+    for r in range(n_rel):
+        dst = np.repeat(np.arange(n_targets), fan)
+        src = n_targets + (dst * n_rel + r) * fan + np.tile(np.arange(fan), n_targets)
+        ei[("note", f"rel{r}", "note")] = np.stack([src, dst]).astype(np.int64)
+    g = ScoreGraph(num_nodes={"note": n}, edge_index=ei, batch={"note": np.zeros(n, dtype=np.int64)},
+                   onset_div=np.arange(n, dtype=np.int64), duration_div=np.ones(n, dtype=np.int64))
+    return ScoreStore([g], 25, DEV, tasks={"a": 3}, seed=0)
+
+
+def test_crowded_subgraph_is_deterministic_and_terminates():
+    """1 500 distinct out-of-window candidates in one subgraph (more than the kernel's candidate list, fewer than
+    its table): the cap smallest ids are kept whatever the order of the atomics — bit-identical to the oracle."""
+    from analysisgnn_amd import _lib
+    from analysisgnn_amd.batching import DeviceSampler
+    from oracle import sampler_ref as S
+    T, R, fan, cap = 300, 1, (5, 2), (64, 32)
+    store = _crowded_store(T, R, fan[0])
+    smp = DeviceSampler(store, 1, T, fan, cap, seed=5)
+    wins = np.array([0], dtype=np.int32)
+    smp.set_windows(wins)
+    batch = smp.sample()
+    torch.cuda.synchronize()
+    rowptr = [c.rowptr.cpu().numpy() for c in store.csr]
+    col = [c.col.cpu().numpy() for c in store.csr]
+    gid, edges, dropped = S.sample_hops(rowptr, col, wins, T, fan, cap, seed=5, step=1)
+    assert dropped == T * R * fan[0] - cap[0]
+    assert np.array_equal(smp.node_gid.cpu().numpy(), gid)
+    for r, et in enumerate(store.edge_types):
+        assert np.array_equal(batch["edge_index_dict"][et].cpu().numpy(), edges[r]), et
+    assert smp.dropped() == dropped
+    _lib.check_device_status(DEV)
+
+
+def test_more_candidates_than_the_table_holds_is_an_error_not_a_hang():
+    """5 000 distinct candidates > the 4 096-entry LDS table: the launch terminates (every probe loop is bounded), the
+    sources that found no place are left out, and the device status word reports it."""
+    from analysisgnn_amd import _lib
+    from analysisgnn_amd.batching import DeviceSampler
+    T, R, fan, cap = 500, 2, (5,), (64,)
+    store = _crowded_store(T, R, fan[0])
+    word = _lib.status_word(DEV)
+    before = int(word.item())
+    smp = DeviceSampler(store, 1, T, fan, cap, seed=5)
+    smp.set_windows(np.array([0], dtype=np.int32))
+    batch = smp.sample()
+    torch.cuda.synchronize()
     assert int(word.item()) > before
     with pytest.raises(_lib.AgnnError):
         _lib.check_device_status(DEV)
     word.zero_()                                                    # leave the shared word clean for the other tests
+    gid = smp.node_gid.cpu().numpy()
+    assert (gid[T:] >= T).all()                                     # the hop block is full of real out-of-window notes
+    for et in store.edge_types:
+        e = batch["edge_index_dict"][et].cpu().numpy()
+        live = e[0] >= 0
+        assert (gid[e[0][live]] >= 0).all() and (e[1][live] < T).all()
 
 
 def test_padded_batch_equals_compact_batch_on_the_model():

@@ -231,3 +231,61 @@ def test_single_stream_captured_step_is_stable_over_many_replays():
     finally:
         graph.index_cache_enabled = was
         _HybridMixin.overlap_sequence_branch = was_overlap
+
+
+@pytest.mark.parametrize("mode", ["accumulate", "flat_views"])
+def test_existing_grads_with_deferred_and_overlapped_weight_grads(mode):
+    """with dp.defer_weight_grads / enable_wgrad_overlap a gradient may only be produced late (or on the weight-
+    gradient stream) while its parameter has no `.grad` — otherwise AccumulateGrad adds at once, on the main stream.  The
+    guard looks through the cats / stacks / packs of parameters (linear.all_steal).  Two micro-batches accumulated into
+    `.grad`, and FlatGradBuffer(views=True) (gradients pre-set as views): bit-identical to the plain schedule."""
+    from analysisgnn_amd import dp, graph
+    from analysisgnn_amd.heads import MultiTaskLoss, training_loss
+    from analysisgnn_amd.linear import join_wgrad
+    from analysisgnn_amd.models import TorchAnalysisGNN
+    from analysisgnn_amd.synth import make_batch, torch_inputs
+    dev = torch.device("cuda", 0)
+    tasks = {"cadence": 4, "localkey": 50, "hrythm": 2}
+    batches = []
+    for seed in (0, 1):
+        g = make_batch(5, 500, first_seed=10 * seed)
+        I = torch_inputs(g, 25, dev, seed=seed)
+        labels = torch.stack([torch.randint(0, c, (I["batch_size"],), generator=torch.Generator().manual_seed(7 * seed + i)).to(dev)
+                              for i, c in enumerate(tasks.values())])
+        batches.append((I, labels))
+    torch.manual_seed(0)
+    model = TorchAnalysisGNN(g.metadata(), 25, 256, 128, tasks, 3, dropout=0.0, use_jk=False, logit_fusion=False).to(dev).train()
+    clf = MultiTaskLoss(list(tasks)).to(dev)
+    both = torch.nn.ModuleDict({"m": model, "c": clf})
+    params = [p for p in both.parameters() if p.requires_grad]
+    was = graph.index_cache_enabled
+    graph.index_cache_enabled = False
+    flat = dp.FlatGradBuffer(params, views=True) if mode == "flat_views" else None
+
+    def run(off_chain: bool):
+        dp.enable_wgrad_overlap(off_chain, "all")
+        dp.defer_weight_grads(off_chain)
+        if flat is not None:
+            flat.zero()
+        else:
+            for p in params:
+                p.grad = None
+        for I, labels in batches:
+            x = model.encode(I["pitch_spelling"], I["key_signature"], I["x_dict"], I["edge_index_dict"], I["batch_dict"], I["batch_size"],
+                             None, None)
+            logits, offs, _ = model.forward_clf_fused(x)
+            loss, _ = training_loss(logits, offs, labels, x, 0.1, 0.1, -1, task_params=clf.weights())
+            loss.backward()
+        join_wgrad()
+        torch.cuda.synchronize()
+        return [p.grad.detach().clone() for p in params]
+    try:
+        g0 = run(False)
+        g1 = run(True)
+        assert all(torch.isfinite(t).all() for t in g0) and max(float(t.abs().max()) for t in g0) > 0
+        for a, b, (name, _) in zip(g0, g1, both.named_parameters()):
+            assert torch.equal(a, b), (name, float((a - b).abs().max()))
+    finally:
+        dp.defer_weight_grads(False)
+        dp.enable_wgrad_overlap(False)
+        graph.index_cache_enabled = was
