@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # AGNN_LIB: another build of the same C-ABI (scripts/csr_memset_probe.py loads the memset-probe variant); normally unset
-LIB_PATH = os.environ.get("AGNN_LIB") or os.path.join(_HERE, "libagnn_hip.so")
+LIB_PATH = os.path.join(_HERE, "libagnn_hip.so")
 MAX_SEG = 32
 
 SPMM_MEAN, SPMM_SKIP_SELF, SPMM_ACCUM = 1, 2, 4

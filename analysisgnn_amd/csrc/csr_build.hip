@@ -301,17 +301,10 @@ extern "C" int agnn_csr_build(int n_seg, const agnn_coo_seg_t* segs, int32_t* ro
   size_t temp_bytes = l.temp_bytes;
 
   hipError_t e = hipSuccess;
-#ifdef AGNN_CSR_MEMSET_PROBE
-  // scripts/csr_memset_probe.py only (libagnn_hip_memsetprobe.so): round 1's way of clearing the counters, kept to check
-  // with the status word whether a memset node leaves them stale under graph replay.  Never in libagnn_hip.so.
-  e = hipMemsetAsync(cnt, 0, static_cast<size_t>(r_total + 2) * sizeof(uint32_t), stream);
-  if (e != hipSuccess) return fail(AGNN_ERUNTIME, "csr_build/memset: %s", hipGetErrorString(e));
-#else
   int blocks_z = static_cast<int>((r_total + 2 + threads - 1) / threads);
   if (blocks_z > 2048) blocks_z = 2048;
   hipLaunchKernelGGL(k_zero_u32, dim3(blocks_z), dim3(threads), 0, stream, cnt, r_total + 2);
   if (int rc = check_launch("csr_build/zero")) return rc;
-#endif
   int blocks = static_cast<int>((e_total + threads - 1) / threads);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(k_count, dim3(blocks), dim3(threads), 0, stream, t, keys, cnt);

@@ -215,9 +215,8 @@ extern "C" int agnn_embed_cat_bwd_f32(const float* dout, int64_t ld_dout, int32_
   a.v_total = vt; a.v_pad = vt;
   a.slab = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t{255});
   hipStream_t s = static_cast<hipStream_t>(stream_);
-  static const bool old_kernel = getenv("AGNN_EMBED_BWD_OLD") != nullptr;      // A/B switch
   const int ncg = (n_tab * dim + 63) / 64;
-  if (static_cast<int64_t>(vt) * dim <= kEmbLdsFloats && ncg <= 4 && !old_kernel) {
+  if (static_cast<int64_t>(vt) * dim <= kEmbLdsFloats && ncg <= 4) {
     if (ncg == 1) hipLaunchKernelGGL(k_embed_bwd_rows<1>, dim3(kSlices), dim3(256), 0, s, a);
     else if (ncg == 2) hipLaunchKernelGGL(k_embed_bwd_rows<2>, dim3(kSlices), dim3(256), 0, s, a);
     else if (ncg == 3) hipLaunchKernelGGL(k_embed_bwd_rows<3>, dim3(kSlices), dim3(256), 0, s, a);

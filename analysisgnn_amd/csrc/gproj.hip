@@ -109,29 +109,22 @@ __global__ __launch_bounds__(256) void k_gproj_fwd(GpArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Whole-row forward (K = 64): one workgroup (8 waves) = 64 rows x ALL groups, so a logits row leaves one CU.
-// profiles/r01_gproj_pmc.md: in the kernel above a row is written by 21 workgroups on different XCDs (one per group) in
-// 8 ... 740-byte strips, ~20 of its 60 us go to those stores, and its phases (stage `a`, stage a weight tile, 32 dependent
-// MFMAs, store) are serial with ~3 workgroups per CU.  Here:
-//   * `a` streams through LDS in chunks of 256 columns (four groups): one wave instruction reads 1 KB of ONE row (the access
-//     shape the norm kernels reach 5 TB/s with), 8 rows per wave and chunk, into a 64 x 260-float image (row stride 65 x 16
-//     bytes: the 16-byte fragment reads of 16 rows hit 16 different bank groups); chunk c + 1 is in registers while chunk c
-//     is computed; the chunk's logits are assembled in a 64 x 308-float image and leave as whole row pieces (256
-//     contiguous bytes per store instruction instead of four 64-byte pieces); two barriers per chunk.
-//     (Fragments read straight from global memory — 64-byte pieces of 16 rows per
-//     instruction — cost 31 of 55 us: profiles/r02_gproj.md.)
+// Whole-row kernels (K = 64): a logits row leaves ONE CU.  profiles/r01_gproj_pmc.md: in the kernel above a row is written
+// by 21 workgroups on different XCDs (one per group) in 8 ... 740-byte strips, ~20 of its 60 us go to those stores.  The
+// tile scheme the whole-row kernels share (the first of them, a 64-row workgroup per launch, was replaced by the persistent
+// kernel below: profiles/r02_gproj.md):
+//   * `a` streams through an LDS image in chunks of groups, one wave instruction reading 1 KB of ONE row;
 //   * v_mfma_f32_16x16x4_f32 tiles, 16 rows x 16 classes: classes are padded to 16 instead of 32 (848 instead of 1088
 //     padded classes for the 21 heads).  Lane (i = lane & 15, q = lane >> 4) owns k = 16u + 4q + e (u, e < 4) of BOTH
 //     operands — any k order serves as long as A and B agree — so the four float4 of a lane ARE its 16 operand registers;
-//   * the 16-class tiles of a chunk's groups go round-robin to the 8 waves; a weight tile (16 classes x 64 = 4 KB, L2) is
-//     fetched once per 64 rows — while the wave's previous tile is computed — and used by four row tiles (64 MFMAs);
+//   * the 16-class tiles of a chunk's groups go round-robin to the multiplier waves; a weight tile (16 classes x 64 = 4 KB,
+//     L2) is fetched while the wave's previous tile is computed;
 //   * two accumulators per row tile (even / odd k-steps): the 16-step chain is issue-bound (32 cycles), not latency-bound (40).
 // D layout of the 16x16 tile: column = lane & 15 (class), rows 4q + r in register r.
 // ------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kGpMaxTiles16 = 128;      // capacity of the flat tile list (host: n_tiles32 <= 64, a 32-class tile is at most two)
-constexpr int kGpLdA = 260;             // floats per LDS row of a chunk of `a` (256 + 4)
 constexpr int kGpLdO = 308;             // floats per LDS row of a chunk of logits (4 * 308 = 16 mod 64 banks)
 
 struct GpWTile {
@@ -166,9 +159,6 @@ __device__ __forceinline__ void gp_rowtile16(const GpArgs& p, const float4 (&af)
   // A chunk wider than the LDS image: straight to global memory, 64-byte pieces.  Unconditional: a lane past the group's
   // classes computed class C - 1 again (its weight row was clamped) and a lane past the last row computed the last row
   // again, so writing to the clamped address repeats a correct value.
-#ifdef GP_ABL_ST
-  if (acc0[0] != 123.456f) return;
-#endif
   const int cs = c < r.C ? c : r.C - 1;
   float* op = p.out + r.off + cs;
 #pragma unroll
@@ -177,140 +167,6 @@ __device__ __forceinline__ void gp_rowtile16(const GpArgs& p, const float4 (&af)
     ro = ro < p.n_rows ? ro : p.n_rows - 1;
     op[ro * p.ld_out] = acc0[rr] + acc1[rr] + bias_on * r.bias;
   }
-}
-
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gproj_fwd_rows(GpArgs p) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * 64;
-  const int i = lane & 15, q = lane >> 4;
-  __shared__ __attribute__((aligned(16))) float sA[64 * kGpLdA];
-  __shared__ float sO[64 * kGpLdO];
-  __shared__ uint32_t s_tiles[8][kGpMaxTiles16];
-  // group table in lanes (lane g: group g's column range, the flat index of its first 16-class tile) and the flat tile
-  // list (group | tile << 8) in this wave's LDS slice
-  const int gl = lane < p.G ? lane : p.G - 1;
-  const int c0 = p.seg_off[gl], c1 = p.seg_off[gl + 1];
-  const int my_nt = lane < p.G ? ((c1 - c0 + 15) >> 4) : 0;
-  int start = 0, T = 0;
-  for (int g = 0; g < p.G; ++g) {
-    start = lane == g ? T : start;
-    T += __builtin_amdgcn_readlane(my_nt, g);
-  }
-  start = lane < p.G ? start : T;                      // lanes >= G: "one past the last tile"
-  for (int t = 0; t < my_nt; ++t) s_tiles[wave][start + t] = static_cast<uint32_t>(lane) | (static_cast<uint32_t>(t) << 8);
-  const int n_chunks = (p.G + 3) >> 2;
-  const float* bias_p = p.b != nullptr ? p.b : p.w;      // no bias: any readable address (the value is multiplied by 0)
-  const float bias_on = p.b != nullptr ? 1.f : 0.f;
-  const int width = p.G * 64;
-  // ---- chunk staging: wave w owns rows 8w .. 8w + 7 of the block, lane l columns 4l .. 4l + 3 of the chunk
-  float4 st0, st1, st2, st3, st4, st5, st6, st7;       // named registers (an array captured by a lambda stays in scratch)
-#define GP_ST_LOAD1(r, c_)                                                                        \
-  {                                                                                               \
-    int64_t row_ = row0 + 8 * wave + (r);                                                         \
-    row_ = row_ < p.n_rows ? row_ : p.n_rows - 1;                                                 \
-    st##r = *reinterpret_cast<const float4*>(p.a + row_ * p.ld_a + (c_));                         \
-  }
-#define GP_STAGE_LOAD(c)                                                                          \
-  {                                                                                               \
-    const int col_ = 256 * (c) + 4 * lane;                                                        \
-    const int cc_ = col_ < width ? col_ : width - 4; /* a narrower last chunk repeats a valid piece */ \
-    GP_ST_LOAD1(0, cc_) GP_ST_LOAD1(1, cc_) GP_ST_LOAD1(2, cc_) GP_ST_LOAD1(3, cc_)               \
-    GP_ST_LOAD1(4, cc_) GP_ST_LOAD1(5, cc_) GP_ST_LOAD1(6, cc_) GP_ST_LOAD1(7, cc_)               \
-  }
-#define GP_ST_WRITE1(r, buf) *reinterpret_cast<float4*>(&sA[(8 * wave + (r)) * kGpLdA + 4 * lane]) = st##r;
-#define GP_STAGE_WRITE(buf)                                                                       \
-  {                                                                                               \
-    GP_ST_WRITE1(0, buf) GP_ST_WRITE1(1, buf) GP_ST_WRITE1(2, buf) GP_ST_WRITE1(3, buf)           \
-    GP_ST_WRITE1(4, buf) GP_ST_WRITE1(5, buf) GP_ST_WRITE1(6, buf) GP_ST_WRITE1(7, buf)           \
-  }
-  // ---- this wave's tiles: chunk c owns the flat tiles of groups 4c .. 4c + 3; wave w takes every 8th of them
-  auto chunk_begin = [&](int c) { return __builtin_amdgcn_readlane(start, 4 * c < 63 ? 4 * c : 63); };
-  int nc = 0, nn = chunk_begin(0) + wave;              // the next tile to fetch weights for: chunk, flat index
-  auto settle = [&]() {                                 // move (nc, nn) forward to the wave's next existing tile
-    while (nc < n_chunks && nn >= chunk_begin(nc + 1)) {
-      ++nc;
-      nn = chunk_begin(nc) + wave;
-    }
-  };
-  GpWTile wA, wB;
-  wA.t = wB.t = 0; wA.off = wB.off = 0; wA.C = wB.C = 1; wA.gc = wB.gc = 0;
-  auto fetch_w = [&](GpWTile& o) {                      // weights of tile nn (if any); then advance
-    const uint32_t ds = s_tiles[wave][nn < T ? nn : T - 1];
-    const int g = __builtin_amdgcn_readfirstlane(static_cast<int>(ds & 0xffu));
-    o.t = __builtin_amdgcn_readfirstlane(static_cast<int>(ds >> 8));
-    o.off = __builtin_amdgcn_readlane(c0, g);
-    o.C = __builtin_amdgcn_readlane(c1, g) - o.off;
-    o.gc = g & 3;
-    const int c_ = 16 * o.t + i;
-    const int cc_ = c_ < o.C ? c_ : o.C - 1;
-    const float4* wp = reinterpret_cast<const float4*>(p.w + static_cast<int64_t>(o.off + cc_) * 64 + 4 * q);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) o.w[u] = wp[4 * u];
-    o.bias = bias_p[o.off + cc_];
-    nn += 8;
-    settle();
-  };
-  GP_STAGE_LOAD(0)
-  settle();
-  int cur_c = nc, cur_n = nn;                          // the tile whose weights sit in wA
-  fetch_w(wA);
-  GP_STAGE_WRITE(0)
-  __syncthreads();
-  for (int c = 0; c < n_chunks; ++c) {
-    if (c + 1 < n_chunks) GP_STAGE_LOAD(c + 1)
-    const float* sa = sA;
-    const int chunk_off = __builtin_amdgcn_readlane(c0, 4 * c), g_end = 4 * c + 4 < p.G ? 4 * c + 4 : p.G;
-    const int chunk_w = __builtin_amdgcn_readlane(c1, g_end - 1) - chunk_off;
-    float* so = chunk_w <= kGpLdO ? sO : nullptr;
-    // tiles of this chunk that are this wave's, two per trip (the weight register sets alternate)
-    while (cur_c == c && cur_n < T) {
-      int nxt_c = nc, nxt_n = nn;
-      fetch_w(wB);
-      {
-        float4 af[4][4];
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            af[rt][u] = *reinterpret_cast<const float4*>(&sa[(16 * rt + i) * kGpLdA + wA.gc * 64 + 16 * u + 4 * q]);
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) gp_rowtile16(p, af[rt], wA, bias_on, i, q, row0, 16 * rt, so, chunk_off);
-      }
-      cur_c = nxt_c; cur_n = nxt_n;
-      if (!(cur_c == c && cur_n < T)) {                  // the tile in wB belongs to a later chunk: keep it as wA
-        wA = wB;
-        break;
-      }
-      nxt_c = nc; nxt_n = nn;
-      fetch_w(wA);
-      {
-        float4 af[4][4];
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            af[rt][u] = *reinterpret_cast<const float4*>(&sa[(16 * rt + i) * kGpLdA + wB.gc * 64 + 16 * u + 4 * q]);
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) gp_rowtile16(p, af[rt], wB, bias_on, i, q, row0, 16 * rt, so, chunk_off);
-      }
-      cur_c = nxt_c; cur_n = nxt_n;
-    }
-    __syncthreads();                                   // every tile of the chunk is done: sO complete, sA free
-    if (c + 1 < n_chunks) GP_STAGE_WRITE(0)
-    if (so != nullptr) {                                // whole row pieces: 256 contiguous bytes per store instruction
-      for (int r = 0; r < 8; ++r) {
-        const int64_t ro = row0 + 8 * wave + r;
-        if (ro >= p.n_rows) break;
-        for (int col = lane; col < chunk_w; col += 64) p.out[ro * p.ld_out + chunk_off + col] = so[(8 * wave + r) * kGpLdO + col];
-      }
-    }
-    __syncthreads();                                   // sA holds chunk c + 1, sO may be overwritten
-  }
-#undef GP_ST_LOAD1
-#undef GP_STAGE_LOAD
-#undef GP_ST_WRITE1
-#undef GP_STAGE_WRITE
 }
 
 // ------------------------------------------------------------------------------------------
@@ -332,24 +188,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // ------------------------------------------------------------------------------------------
 constexpr int kGpLdA16 = 1028;          // floats per LDS row of a chunk (1024 + 4: 16-byte fragments of 16 rows, 16 bank groups)
 
-// Study builds (never the shipped library): -DGP_STAMPS records s_memtime per wave and phase (scripts/gproj_stamps.py reads
-// them through agnn_debug_gproj_stamps); -DGP_ABL_A / _W / _ST drop the `a` loads / the weight traffic / the logits stores.
-#ifdef GP_STAMPS
-__device__ unsigned long long g_gp_stamps[32 * 12 * 16];     // [workgroup < 32][wave][16]
-#define GP_STAMP() { if ((threadIdx.x & 63) == 0 && blockIdx.x < 32 && n_st_ < 16) g_gp_stamps[(blockIdx.x * 12 + (threadIdx.x >> 6)) * 16 + n_st_] = __builtin_amdgcn_s_memtime(); ++n_st_; }
-#else
-#define GP_STAMP()
-#endif
-#ifdef GP_ABL_W
-#define GP_WOFF(x) 0
-#else
-#define GP_WOFF(x) (x)
-#endif
 
 template <int NQ>                         // 256-column quarters per chunk (host: ceil(groups per chunk / 4))
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_gproj_fwd_rows32(GpArgs p, int CG, int n_chunks) {
-  [[maybe_unused]] int n_st_ = 0;
-  GP_STAMP()
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool mover = wave >= 8;
@@ -382,25 +223,17 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   if (mover) {
     int rb = blockIdx.x;
     GP_MOVE_LOAD(rb, 0)
-    GP_STAMP()
     GP_MOVE_WRITE()
     __syncthreads();
-    GP_STAMP()
     for (; rb < n_rb; rb += gridDim.x) {
       for (int c = 0; c < n_chunks; ++c) {
         const bool more = c + 1 < n_chunks || rb + static_cast<int>(gridDim.x) < n_rb;
         if (!more) break;
         const int nx_rb = c + 1 < n_chunks ? rb : rb + static_cast<int>(gridDim.x), nx_c = c + 1 < n_chunks ? c + 1 : 0;
-#ifdef GP_ABL_A
-        if (p.n_rows < 0)
-#endif
         GP_MOVE_LOAD(nx_rb, nx_c)
-        GP_STAMP()
         __syncthreads();                               // every tile of the chunk has read its fragments
-        GP_STAMP()
         GP_MOVE_WRITE()
         __syncthreads();
-        GP_STAMP()
       }
     }
     return;
@@ -433,7 +266,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     WT.gc = g_ - (CH) * CG;                                                                         \
     const int c_ = 16 * WT.t + i;                                                                  \
     const int cc_ = c_ < WT.C ? c_ : WT.C - 1;                                                      \
-    const float4* wp_ = reinterpret_cast<const float4*>(p.w + static_cast<int64_t>(GP_WOFF(WT.off) + cc_) * 64 + 4 * q); \
+    const float4* wp_ = reinterpret_cast<const float4*>(p.w + static_cast<int64_t>(WT.off + cc_) * 64 + 4 * q); \
     WT.w[0] = wp_[0]; WT.w[1] = wp_[4]; WT.w[2] = wp_[8]; WT.w[3] = wp_[12];                          \
     WT.bias = bias_p[WT.off + cc_];                                                                 \
   }
@@ -446,12 +279,10 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     _Pragma("unroll") for (int rt = 0; rt < 2; ++rt) gp_rowtile16(p, f_[rt], WT, bias_on, i, q, row0, 16 * rt, nullptr, 0); \
   }
   int rb = blockIdx.x;
-  GP_STAMP()
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // this wave's tile list is read back below
   __builtin_amdgcn_wave_barrier();
   GP_W_FETCH(wA, 0, 0)
   __syncthreads();
-  GP_STAMP()
   for (; rb < n_rb; rb += gridDim.x) {
     const int64_t row0 = static_cast<int64_t>(rb) * 32;
     for (int c = 0; c < n_chunks; ++c) {
@@ -468,12 +299,9 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         GP_TILE(wB)
       }
       if (n_slots == 0) GP_W_FETCH(wA, nx_c, 0)           // (a chunk of class-less groups)
-      GP_STAMP()
       if (more) {
         __syncthreads();
-        GP_STAMP()
         __syncthreads();                               // the movers have rewritten the image
-        GP_STAMP()
       }
     }
   }
@@ -639,8 +467,6 @@ struct GdStep {                           // wave-uniform description of one ste
 template <int NJ>                         // 64-column pieces per row of dout (host: ceil(sum_c / 64))
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_gproj_dx_rows(GpArgs p) {
   constexpr int ld_img = kGpDxLd;
-  [[maybe_unused]] int n_st_ = 0;
-  GP_STAMP()
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool mover = wave >= 8;
@@ -684,16 +510,12 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     GD_PC(8) GD_PC(9) GD_PC(10) GD_PC(11) GD_PC(12) GD_PC(13) GD_PC(14) GD_PC(15)
     GD_ALL(GD_WRITE1, 0)
     __syncthreads();                                     // the first block is in the image
-    GP_STAMP()
     for (int rb = blockIdx.x; rb + static_cast<int>(gridDim.x) < n_rb; rb += gridDim.x) {
       GD_ALL(GD_LOAD1, rb + gridDim.x)
-      GP_STAMP()
       __syncthreads();                                   // every unit of the block has been multiplied
-      GP_STAMP()
       GD_ALL(GD_WRITE1, 0)
       if (wave == 8 && lane == 0) s_next = 0;
       __syncthreads();
-      GP_STAMP()
     }
     return;
   }
@@ -730,7 +552,6 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
   __syncthreads();
   __syncthreads();
-  GP_STAMP()
   for (int rb = blockIdx.x; rb < n_rb; rb += gridDim.x) {
     const int64_t row0 = static_cast<int64_t>(rb) * 32;
     // the request stream: unit (fg, frt) with fsteps steps, fs the next one to request
@@ -760,8 +581,8 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int k_ = 16 * fs + 4 * q;                                                               \
     const int hi_ = fC > 0 ? fC - 1 : 0;                                                          \
     const float* wg_ = p.w + 4 * i;                                                               \
-    int r0_ = GP_WOFF(foff) + (k_ < hi_ ? k_ : hi_), r1_ = GP_WOFF(foff) + (k_ + 1 < hi_ ? k_ + 1 : hi_);         \
-    int r2_ = GP_WOFF(foff) + (k_ + 2 < hi_ ? k_ + 2 : hi_), r3_ = GP_WOFF(foff) + (k_ + 3 < hi_ ? k_ + 3 : hi_); \
+    int r0_ = foff + (k_ < hi_ ? k_ : hi_), r1_ = foff + (k_ + 1 < hi_ ? k_ + 1 : hi_);         \
+    int r2_ = foff + (k_ + 2 < hi_ ? k_ + 2 : hi_), r3_ = foff + (k_ + 3 < hi_ ? k_ + 3 : hi_); \
     r0_ = r0_ < p.sum_c ? r0_ : p.sum_c - 1; r1_ = r1_ < p.sum_c ? r1_ : p.sum_c - 1;             \
     r2_ = r2_ < p.sum_c ? r2_ : p.sum_c - 1; r3_ = r3_ < p.sum_c ? r3_ : p.sum_c - 1;             \
     B##0 = *reinterpret_cast<const float4*>(wg_ + static_cast<int64_t>(r0_) * 64);                \
@@ -801,11 +622,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       }                                                                                           \
     }                                                                                             \
   }
-#ifdef GP_ABL_ST
-#define GD_STORE(ptr, v) if (acc0[0] == 123.456f) *(ptr) = (v);
-#else
 #define GD_STORE(ptr, v) *(ptr) = (v);
-#endif
     GD_GRAB()
     GD_NEXT(d0, x)
     GD_NEXT(d1, y)
@@ -818,12 +635,9 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       if (!d2.valid) break;
       GD_STEP(d2, z, d0, d1, y)
     }
-    GP_STAMP()
     if (rb + static_cast<int>(gridDim.x) < n_rb) {
       __syncthreads();
-      GP_STAMP()
       __syncthreads();                                   // the movers have rewritten the image and reset the counter
-      GP_STAMP()
     }
   }
 #undef GD_DECL
@@ -838,24 +652,6 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #undef GD_FRAG
 #undef GD_STEP
 #undef GD_STORE
-}
-
-// A/B switch for scripts/bench_gproj.py: AGNN_GPROJ_FWD=1 -> one group per workgroup (round 1), 3 -> 64-row workgroups with
-// four-group chunks; anything else -> the persistent wave-specialised kernel
-int flags_fwd_variant() {
-  static const int v = [] {
-    const char* e = getenv("AGNN_GPROJ_FWD");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
-}
-
-int flags_dx_variant() {                   // AGNN_GPROJ_DX=1: the one-wave-per-(row tile, group) kernel
-  static const int v = [] {
-    const char* e = getenv("AGNN_GPROJ_DX");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
 }
 
 int cu_count() {                          // compute units of the current device (one persistent workgroup each)
@@ -898,11 +694,6 @@ int check_common(const char* what, const void* a, int64_t ld_a, const void* w, c
 
 }  // namespace
 
-#ifdef GP_STAMPS
-extern "C" int agnn_debug_gproj_stamps(unsigned long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gp_stamps), sizeof(g_gp_stamps)) == hipSuccess ? 0 : -1;
-}
-#endif
 
 extern "C" int agnn_gproj_fwd_f32(const float* a, int64_t ld_a, const float* w, const float* b, const int32_t* seg_off,
                                   int32_t n_groups, int32_t K, int32_t n_tiles32, int64_t n_rows, float* out, int64_t ld_out,
@@ -916,8 +707,8 @@ extern "C" int agnn_gproj_fwd_f32(const float* a, int64_t ld_a, const float* w, 
   p.ld_a = ld_a; p.ld_out = ld_out; p.n_rows = n_rows; p.G = n_groups;
   p.n_row_tiles = static_cast<int32_t>((n_rows + 31) / 32);
   hipStream_t s = static_cast<hipStream_t>(stream_);
-  if (K == 64 && n_groups <= 32 && n_tiles32 <= kGpMaxTiles16 / 2 && flags_fwd_variant() != 1) {   // whole-row kernel
-    if (flags_fwd_variant() != 3) {                     // AGNN_GPROJ_FWD=3: the 64-row kernel; =1: one group per workgroup
+  if (K == 64 && n_groups <= 32 && n_tiles32 <= kGpMaxTiles16 / 2) {   // whole-row kernel (other shapes: one group per workgroup)
+    {
       const int n_chunks = (n_groups + 15) / 16, CG = (n_groups + n_chunks - 1) / n_chunks, NQ = (CG + 3) / 4;
       const int64_t n_rb = (n_rows + 31) / 32;
       const dim3 grid(static_cast<unsigned>(n_rb < cu_count() ? n_rb : cu_count()));
@@ -927,8 +718,6 @@ extern "C" int agnn_gproj_fwd_f32(const float* a, int64_t ld_a, const float* w, 
       else hipLaunchKernelGGL(k_gproj_fwd_rows32<4>, grid, dim3(768), 0, s, p, CG, n_chunks);
       return check_launch("gproj_fwd(rows32)");
     }
-    hipLaunchKernelGGL(k_gproj_fwd_rows, dim3(static_cast<unsigned>((n_rows + 63) / 64)), dim3(512), 0, s, p);
-    return check_launch("gproj_fwd(rows)");
   }
   const int64_t row_blocks = (n_rows + 127) / 128;
   const dim3 grid(static_cast<unsigned>(row_blocks * n_groups));
@@ -962,7 +751,7 @@ extern "C" int agnn_gproj_bwd_f32(const float* dout, int64_t ld_dout, const floa
     p.da = da; p.ld_da = ld_da;
     const int ld_img = sum_c + 15 * n_groups + 4;          // at most: every group padded to 16 classes, + the dump slot
     const bool rows_ok = K == 64 && n_groups <= 32 && sum_c >= 1 && sum_c <= 1024 && ld_img <= kGpDxLd && aligned16(da) && (ld_da & 3) == 0;
-    if (rows_ok && flags_dx_variant() != 1) {            // whole-row kernel
+    if (rows_ok) {                                       // whole-row kernel (other shapes: one wave per (row tile, group))
       const int64_t n_rb = (n_rows + 31) / 32;
       const dim3 grid(static_cast<unsigned>(n_rb < cu_count() ? n_rb : cu_count()));
       switch ((sum_c + 63) / 64) {

@@ -150,8 +150,7 @@ __global__ __launch_bounds__(256) void k_mtce_lds(const float* __restrict__ z, i
 void launch_mtce(hipStream_t s, const float* logits, int64_t ld, const int32_t* seg_off, int n_tasks, const int64_t* labels, int64_t n_rows,
                  float eps, int64_t ignore, float* row_loss, float* dlogits) {
   const unsigned blocks = static_cast<unsigned>((n_rows + 15) / 16);   // 4 waves x 4 rows
-  static const bool plain = getenv("AGNN_MTCE_PLAIN") != nullptr;      // A/B switch (scripts)
-  if (ld > 0 && ld <= kMtceMaxCols && !plain)
+  if (ld > 0 && ld <= kMtceMaxCols)
     hipLaunchKernelGGL(k_mtce_lds, dim3(blocks), dim3(256), static_cast<size_t>(16) * ld * sizeof(float), s, logits, ld, seg_off, n_tasks,
                        labels, n_rows, eps, ignore, row_loss, dlogits);
   else

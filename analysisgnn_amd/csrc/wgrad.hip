@@ -12,8 +12,6 @@
 //   * N is cut into S slices so that (#tiles x S) ~ 2 workgroups per CU; each workgroup writes its partial tile to
 //     a slab and a second tiny kernel sums the S slabs in a fixed order (deterministic, no atomics);
 //   * the bias gradient rides along (column sums of the dY values already in registers).
-#include <cstdlib>
-
 #include "agnn_common.h"
 
 namespace {
@@ -134,114 +132,6 @@ __global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
     bs1 += __shfl_xor(bs1, 32, 64);
     if (kk == 0 && ti == 0)
       *reinterpret_cast<float2*>(a.slab_b + static_cast<int64_t>(slice) * a.out_pad + ocol) = make_float2(bs0, bs1);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// The same tile through LDS (round 2; opt-in, see agnn_wgrad_f32).  In k_wgrad every wave fetches its own operands from global memory — the two waves
-// of a tile row fetch the same dY columns, the two of a tile column the same X columns — with 8-byte loads, and the MFMA
-// pipe is 33 - 44 % busy (profiles/r01_wgrad_mfma.md): load latency between chunks.  Here the workgroup stages 16 rows of
-// its 128 dY and 128 X columns per step with 16-byte loads (each value fetched once per workgroup), two stages ahead
-// (two named register sets, two LDS buffers, ONE barrier per 16 rows = 32 MFMAs per wave), and the waves read their
-// float2 operands from LDS (the 32 lanes of a half read 256 contiguous bytes: no bank conflict).  Rows past the slice are
-// written to LDS as zeros, columns past the matrix are clamped to column 0 (their accumulator rows / columns are never
-// stored).  Needs 16-byte aligned operands and widths / leading dimensions that are multiples of 4.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_wgrad_lds(WgArgs a) {
-  constexpr int RS = 16;                              // rows per stage
-  __shared__ __attribute__((aligned(16))) float sA[2][RS * 128];
-  __shared__ __attribute__((aligned(16))) float sB[2][RS * 128];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int tile = blockIdx.x, slice = blockIdx.y;
-  const int to = tile / a.tiles_in, ti = tile - to * a.tiles_in;
-  const int kk = lane >> 5, c32 = lane & 31;
-  const int r0 = slice * a.rows_per_slice;
-  int r1 = r0 + a.rows_per_slice;
-  if (r1 > a.n) r1 = a.n;
-  // staging role of this thread: rows sr and sr + 8 of the stage, four columns of each operand
-  const int sr = threadIdx.x >> 5, sc = (threadIdx.x & 31) * 4;
-  const int oc = to * 128 + sc, ic = ti * 128 + sc;
-  const uint32_t cb_dy = (oc < a.out_f ? oc : 0) * 4u, cb_x = (ic < a.in_f ? ic : 0) * 4u;
-  const float* dy_s = a.dy + static_cast<int64_t>(r0) * a.ld_dy;
-  const float* x_s = a.x + static_cast<int64_t>(r0) * a.ld_x;
-  const uint32_t ldb_dy = static_cast<uint32_t>(a.ld_dy) * 4u, ldb_x = static_cast<uint32_t>(a.ld_x) * 4u;
-  const int rel_last = a.n - 1 - r0, rows = r1 - r0;
-  const int nst = (rows + RS - 1) / RS;
-  float4 pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;      // two register sets (stages in flight), rows sr and sr + 8
-#define WG_LOAD(A0, A1, B0, B1, st)                                                                                     \
-  {                                                                                                                     \
-    const uint32_t ra_ = static_cast<uint32_t>(min((st) * RS + sr, rel_last)), rb_ = static_cast<uint32_t>(min((st) * RS + sr + 8, rel_last)); \
-    A0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(dy_s) + (ra_ * ldb_dy + cb_dy));                 \
-    A1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(dy_s) + (rb_ * ldb_dy + cb_dy));                 \
-    B0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(x_s) + (ra_ * ldb_x + cb_x));                    \
-    B1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(x_s) + (rb_ * ldb_x + cb_x));                    \
-  }
-#define WG_STORE(A0, A1, B0, B1, st, buf)                                                                               \
-  {                                                                                                                     \
-    const float m0_ = (st) * RS + sr < rows ? 1.f : 0.f, m1_ = (st) * RS + sr + 8 < rows ? 1.f : 0.f;                    \
-    *reinterpret_cast<float4*>(&sA[buf][sr * 128 + sc]) = make_float4(A0.x * m0_, A0.y * m0_, A0.z * m0_, A0.w * m0_);     \
-    *reinterpret_cast<float4*>(&sA[buf][(sr + 8) * 128 + sc]) = make_float4(A1.x * m1_, A1.y * m1_, A1.z * m1_, A1.w * m1_); \
-    *reinterpret_cast<float4*>(&sB[buf][sr * 128 + sc]) = B0;                                                           \
-    *reinterpret_cast<float4*>(&sB[buf][(sr + 8) * 128 + sc]) = B1;                                                     \
-  }
-  f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-  float bs0 = 0.f, bs1 = 0.f;
-  const int ao = wm * 64 + 2 * c32, bo = wn * 64 + 2 * c32;
-#define WG_COMPUTE(buf)                                                                                                  \
-  {                                                                                                                     \
-    float2 av_[8], bv_[8];                                                                                              \
-    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                                     \
-      av_[u] = *reinterpret_cast<const float2*>(&sA[buf][(2 * u + kk) * 128 + ao]);                                       \
-      bv_[u] = *reinterpret_cast<const float2*>(&sB[buf][(2 * u + kk) * 128 + bo]);                                       \
-    }                                                                                                                   \
-    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                                     \
-      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[u].x, bv_[u].x, acc00, 0, 0, 0);                                   \
-      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[u].x, bv_[u].y, acc01, 0, 0, 0);                                   \
-      acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[u].y, bv_[u].x, acc10, 0, 0, 0);                                   \
-      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[u].y, bv_[u].y, acc11, 0, 0, 0);                                   \
-      bs0 += av_[u].x;                                                                                                  \
-      bs1 += av_[u].y;                                                                                                  \
-    }                                                                                                                   \
-  }
-  if (nst > 0) {
-    WG_LOAD(pa0, pa1, pb0, pb1, 0)
-    WG_LOAD(qa0, qa1, qb0, qb1, 1)
-    WG_STORE(pa0, pa1, pb0, pb1, 0, 0)
-    __syncthreads();
-    for (int st = 0; st < nst; st += 2) {
-      // even stage: its data sits in LDS buffer 0, stage st + 1 in register set q, stage st + 2 is fetched into set p
-      WG_LOAD(pa0, pa1, pb0, pb1, st + 2)
-      WG_COMPUTE(0)
-      WG_STORE(qa0, qa1, qb0, qb1, st + 1, 1)
-      __syncthreads();
-      if (st + 1 >= nst) break;
-      WG_LOAD(qa0, qa1, qb0, qb1, st + 3)
-      WG_COMPUTE(1)
-      WG_STORE(pa0, pa1, pb0, pb1, st + 2, 0)
-      __syncthreads();
-    }
-  }
-#undef WG_LOAD
-#undef WG_STORE
-#undef WG_COMPUTE
-  // epilogue: as k_wgrad
-  float* slab = a.slab + (static_cast<int64_t>(slice) * a.out_pad) * a.in_pad;
-  const int ob = to * 128 + wm * 64, ib = ti * 128 + wn * 64;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int i = (r & 3) + 8 * (r >> 2) + 4 * kk;
-    float* row0 = slab + static_cast<int64_t>(ob + 2 * i) * a.in_pad + ib + 2 * c32;
-    float* row1 = row0 + a.in_pad;
-    *reinterpret_cast<float2*>(row0) = make_float2(acc00[r], acc01[r]);
-    *reinterpret_cast<float2*>(row1) = make_float2(acc10[r], acc11[r]);
-  }
-  if (a.slab_b != nullptr && wn == 0) {
-    bs0 += __shfl_xor(bs0, 32, 64);                  // the two lane halves hold the two n parities
-    bs1 += __shfl_xor(bs1, 32, 64);
-    const int ocol = ob + 2 * c32;
-    if (kk == 0 && ti == 0) *reinterpret_cast<float2*>(a.slab_b + static_cast<int64_t>(slice) * a.out_pad + ocol) = make_float2(bs0, bs1);
   }
 }
 
@@ -366,14 +256,9 @@ extern "C" int agnn_wgrad_f32(const float* dy, int64_t ld_dy, const float* x, in
   WgArgs a{dy, x, ld_dy, ld_x, static_cast<int32_t>(n), out_f, in_f, p.rows_per_slice, p.tiles_in, slab,
            db ? slab_b : nullptr, p.out_pad, p.in_pad};
   hipStream_t s = static_cast<hipStream_t>(stream_);
-  // k_wgrad_lds is opt-in: alone it is ~5 % faster on the large shapes (256 x 1280: 109 vs 115 us, scripts/wgrad_shapes.py),
-  // inside the training step — next to the recurrence kernels, whose workgroups hold most of a CU's LDS — the step is
-  // slower with it (3.44 vs 3.37 ms)
-  static const bool use_lds = getenv("AGNN_WGRAD_LDS") != nullptr;
-  const bool lds_ok = use_lds && ((out_f | in_f) & 3) == 0 && ((ld_dy | ld_x) & 3) == 0 &&
-                      ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) & 15u) == 0;
-  if (lds_ok) hipLaunchKernelGGL(k_wgrad_lds, dim3(p.tiles_out * p.tiles_in, p.S), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(k_wgrad, dim3(p.tiles_out * p.tiles_in, p.S), dim3(256), 0, s, a);
+  // (an LDS-staged variant of the tile, round 2, was ~5 % faster alone and slower inside the training step, next to the
+  // recurrence kernels whose workgroups hold most of a CU's LDS: profiles/r01_wgrad_mfma.md; it is not in the library)
+  hipLaunchKernelGGL(k_wgrad, dim3(p.tiles_out * p.tiles_in, p.S), dim3(256), 0, s, a);
   if (int rc = check_launch("wgrad")) return rc;
   return launch_slab_reduce(slab, db ? slab_b : nullptr, p.S, out_f, in_f, p.out_pad, p.in_pad, dw, ld_dw, db, s);
 }

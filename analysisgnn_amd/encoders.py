@@ -263,7 +263,7 @@ def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
     return _SIDE_STREAMS[idx]
 
 
-LATE_SEQUENCE_BACKWARD = os.environ.get("AGNN_SEQ_LATE", "1") == "1"  # A/B: the sequence branch behind a late-created node (_LateNode)
+LATE_SEQUENCE_BACKWARD = True   # the sequence branch behind a late-created node (_LateNode); bench.py --schedule measures both
 
 
 class _Stamp(torch.autograd.Function):

@@ -87,8 +87,16 @@ def leaf_refs(*ts) -> tuple:
 def all_steal(refs) -> bool:
     """Checked in an op's BACKWARD, right before it decides to produce a gradient late or on another stream.  (A parameter
     used TWICE in one graph cannot be seen from here — autograd's input buffer then adds the two gradients on the main
-    stream; such models must not enable the overlap / deferral.)"""
-    return all(_steals(p) for p in refs)
+    stream; such models must not enable the overlap / deferral.)
+    A parameter that already HAS a gradient may have got it from an earlier backward pass of the same accumulation window,
+    whose late work (deferred closures, the weight-gradient stream) has not been joined yet: AccumulateGrad would add onto a
+    tensor that is still being written.  So the first "no" of a backward pass joins everything outstanding — closures run,
+    the current stream waits for the side streams; no host synchronisation."""
+    if all(_steals(p) for p in refs):
+        return True
+    if _DEFER["pending"] or _WG["dirty"] or _WG.get("join"):
+        join_wgrad()
+    return False
 
 
 class wgrad_stream:

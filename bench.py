@@ -75,6 +75,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-wgrad-overlap", action="store_true", help="A/B only: weight gradients on the main stream")
     ap.add_argument("--library-wgrad", action="store_true", help="A/B only: weight gradients through the library GEMM")
     ap.add_argument("--blas", default=None, choices=[None, "hipblaslt", "rocblas"], help="A/B only: torch's preferred BLAS library")
+    ap.add_argument("--graph-dot", default=None, help="debugging: write the captured step's dependency graph as DOT to this path")
+    ap.add_argument("--host-times", action="store_true", help="debugging: report the host time inside the replay calls")
     ap.add_argument("--no-other", action="store_true", help="skip the secondary (whole-graph C2) measurement of the default run")
     return ap.parse_args(argv)
 
@@ -312,7 +314,7 @@ def main():
             torch.cuda.current_stream(dev).wait_stream(side)
             dp.barrier_and_sync()                               # no collective in flight on any rank while capturing
             g2 = torch.cuda.CUDAGraph()
-            dot = os.environ.get("AGNN_GRAPH_DOT")               # the captured step's dependency graph as DOT (debugging)
+            dot = args.graph_dot                                 # the captured step's dependency graph as DOT (debugging)
             # Which of the two backward schedules of the hybrid encoders replays faster depends on how many nodes each
             # branch of the captured graph has (profiles/r02_step_timeline.md: c2s 3.39 vs 3.45 ms, c2 3.61 vs 3.54 ms), so
             # both are captured and the faster one (6 replays each, slowest rank decides) is kept — TunableOp's way.
@@ -372,7 +374,7 @@ def main():
         update()
         return loss
 
-    HOST_T = [] if os.environ.get("AGNN_HOST_TIMES") else None     # debugging: host time inside the two replay calls of a step
+    HOST_T = [] if args.host_times else None           # debugging: host time inside the two replay calls of a step
     for _ in range(args.warmup):
         step()
     dp.barrier_and_sync()

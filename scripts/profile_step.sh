@@ -6,7 +6,7 @@ TAG=$1; shift
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
-AGNN_GRAPH_DOT=$OUT/step.dot python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-other "$@" > /dev/null 2>&1 || true
+python3 $R/bench.py --graph-dot $OUT/step.dot --steps 3 --warmup 2 --no-cpu-baseline --no-other "$@" > /dev/null 2>&1 || true
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT -o c --output-format csv -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-other "$@" > $OUT/bench.log 2>&1
 cd $R
