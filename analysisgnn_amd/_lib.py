@@ -113,6 +113,10 @@ SIGNATURES = {
     "agnn_relt_dw_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int64]),
     "agnn_relt_dw_f32": (C.c_int, [C.c_int, C.POINTER(ReltItem), C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_size_t,
                                   C.c_void_p]),
+    "agnn_absdiff_fwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                       C.c_void_p]),
+    "agnn_absdiff_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                       C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "agnn_gated_fwd_f32": (C.c_int, [C.POINTER(Gated), C.c_void_p, C.c_int64, C.c_void_p]),
     "agnn_gated_bwd_dst_f32": (C.c_int, [C.POINTER(Gated), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "agnn_gated_bwd_src_f32": (C.c_int, [C.POINTER(Gated), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),

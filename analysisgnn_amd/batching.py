@@ -128,11 +128,18 @@ class DeviceSampler:
         for the previous step, and the host then cannot run ahead of the device any more."""
         if not hasattr(self, "_ring"):
             self._ring = [torch.empty(self.n_sub, dtype=torch.int32).pin_memory() for _ in range(16)]
+            self._ring_ev = [None] * len(self._ring)       # per slot: the event behind the copy that last read it
             self._ring_pos = 0
-        buf = self._ring[self._ring_pos]
-        self._ring_pos = (self._ring_pos + 1) % len(self._ring)
+        k = self._ring_pos
+        self._ring_pos = (k + 1) % len(self._ring)
+        if self._ring_ev[k] is not None:
+            self._ring_ev[k].synchronize()                 # a host 16 steps ahead waits here instead of overwriting a slot in flight
+        buf = self._ring[k]
         buf.numpy()[:] = win_start
         self.win_start.copy_(buf, non_blocking=True)
+        ev = self._ring_ev[k] or torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.store.device))
+        self._ring_ev[k] = ev
 
     def dropped(self) -> int:
         """Sources cut by the hop capacities since this sampler was created (synchronises; a statistic, not an error)."""

@@ -477,11 +477,52 @@ class HeteroConv(_HeteroPerRelation):
         return self._run(x, edge_index, edge_type, edge_features)
 
 
+class _RelEdgeAggregate(torch.autograd.Function):
+    """(S, D): S_i = sum_{(i,j)} h_j,  D_i = sum_{(i,j)} |h_i - h_j|, side by side in ONE [N, 2F] matrix (agnn_absdiff_*).
+    `want_d=False`: S only ([N, F]) — the caller brings its own per-edge features."""
+
+    @staticmethod
+    def forward(ctx, fwd: Csr, bwd: Csr, h, want_d: bool):
+        dev = _lib.require_gpu(h)
+        lib = _lib.load()
+        h = h.contiguous()
+        n, F_ = h.shape
+        out = torch.empty((n, 2 * F_ if want_d else F_), dtype=torch.float32, device=dev)
+        _lib.check(lib.agnn_absdiff_fwd_f32(fwd.rowptr.data_ptr(), fwd.col.data_ptr(), h.data_ptr(), h.stride(0), n, F_,
+                                            out.data_ptr(), out.data_ptr() + 4 * F_ if want_d else None, out.stride(0),
+                                            _lib.stream_ptr(dev)), "agnn_absdiff_fwd_f32")
+        ctx.csr, ctx.want_d = (fwd, bwd), want_d
+        ctx.save_for_backward(h)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        fwd, bwd = ctx.csr
+        (h,) = ctx.saved_tensors
+        dev = g.device
+        lib = _lib.load()
+        g = g if (g.stride(1) == 1 and g.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0) else g.contiguous()
+        n, F_ = h.shape
+        dh = torch.empty_like(h)
+        gs, gd = g.data_ptr(), (g.data_ptr() + 4 * F_ if ctx.want_d else None)
+        st = _lib.stream_ptr(dev)
+        if ctx.want_d:       # the aggregating end: gD_i * sum_j sign(h_i - h_j)
+            _lib.check(lib.agnn_absdiff_bwd_f32(fwd.rowptr.data_ptr(), fwd.col.data_ptr(), h.data_ptr(), h.stride(0), n, F_, gd, None,
+                                                g.stride(0), 0, 0, dh.data_ptr(), dh.stride(0), st), "agnn_absdiff_bwd_f32")
+        # the gathered end (transposed CSR): sum_i [ sign(h_j - h_i) * gD_i + gS_i ]
+        _lib.check(lib.agnn_absdiff_bwd_f32(bwd.rowptr.data_ptr(), bwd.col.data_ptr(), h.data_ptr(), h.stride(0), n, F_, gd, gs,
+                                            g.stride(0), 1, 1 if ctx.want_d else 0, dh.data_ptr(), dh.stride(0), st), "agnn_absdiff_bwd_f32")
+        return None, None, dh, None
+
+
 class RelEdgeConv(nn.Module):
     """core/gnn.py:79-106.  h = W_n x + b;  e_ij = |h_i - h_j| unless edge features are given;  m_ij = W_e [h_j || e_ij] + b_e;
     s_i = (h_i + sum_{(i,j)} m_ij) / max(deg_i, 1)  (scatter onto edge row 0 with `out=h.clone()`, mean);  z = W [x || s] + b.
-    The per-edge messages [E, F] are built with library gathers / one GEMM; the scatter-mean with the `out=` numerator
-    runs on the gather-reduce kernel (`scatter.scatter`)."""
+    Re-derived, not transcribed: W_e is linear, so the row sum moves inside it —
+        sum_j m_ij = W_e [ sum_j h_j || sum_j e_ij ] + deg_i b_e
+    — two per-row aggregates from one pass over the neighbours (csrc/reledge.hip) and a NODE-level GEMM [N, 2F] x [2F, F];
+    the reference's [E, F] gathers, the [E, 2F] cat and the edge-level GEMM do not exist here.  Given per-edge features take
+    the same route (their row sums come from the gather-reduce kernel, `scatter.scatter`)."""
 
     def __init__(self, in_node_features, out_features, bias=True, in_edge_features=None):
         super().__init__()
@@ -497,13 +538,24 @@ class RelEdgeConv(nn.Module):
             _xavier_relu_(lin)
 
     def forward(self, features, edge_index, edge_features=None):
-        from .scatter import scatter
         _lib.require_gpu(features)
+        n = features.shape[0]
         h = self.neigh_linear(features)
+        Fh = h.shape[1]
+        if Fh % 4 or Fh > 1024:
+            raise _lib.AgnnError(f"RelEdgeConv: feature width {Fh} (the aggregation kernel takes multiples of 4 up to 1024)")
+        fwd, bwd = build_csr([SegSpec(edge_index[0], edge_index[1], n), SegSpec(edge_index[1], edge_index[0], n)])
+        deg = (fwd.rowptr[1:n + 1] - fwd.rowptr[:n]).to(torch.float32).unsqueeze(1)
         if edge_features is None:
-            edge_features = torch.abs(h[edge_index[0]] - h[edge_index[1]])
-        new_h = self.edge_linear(torch.cat((h[edge_index[1]], edge_features), dim=-1))
-        s = scatter(new_h, edge_index[0], 0, out=h, reduce="mean")      # returns a new tensor: no clone needed
+            agg = _RelEdgeAggregate.apply(fwd, bwd, h, True)                               # [N, 2F] = [S | D]
+        else:
+            from .scatter import scatter
+            e_sum = scatter(edge_features, edge_index[0], 0, dim_size=n, reduce="sum")     # [N, F_e]
+            agg = torch.cat((_RelEdgeAggregate.apply(fwd, bwd, h, False), e_sum), dim=-1)
+        msg = F.linear(agg, self.edge_linear.weight)
+        if self.edge_linear.bias is not None:
+            msg = torch.addcmul(msg, deg, self.edge_linear.bias.unsqueeze(0))              # + deg_i * b_e
+        s = (h + msg) / deg.clamp(min=1.0)
         return self.linear(torch.cat([features, s], dim=-1))
 
 

@@ -16,6 +16,7 @@
  *                         `HeteroConv` (ref: models/cadence.py:147-159,174)
  *   agnn_gru_fwd/bwd_f32  `torch.nn.GRU` of the hybrid sequence branch (ref: models/cadence.py:249-285)
  *   agnn_gated_*          `ResGatedGraphConv` edge gate + scatter (ref: core/gnn.py:246-257)
+ *   agnn_absdiff_*        `RelEdgeConv` per-row sums of h_j and |h_i - h_j| (ref: core/gnn.py:99-105)
  *   agnn_norm_act_*       LayerNorm / ReLU / Dropout chains between the projections (ref: models/analysis.py:429-443)
  *   agnn_wgrad_f32        weight/bias gradients of the dense projections (fp32 MFMA, split over N)
  *   agnn_pack_f32         per-relation parameter cat / sum / gradient fan-out of the fused HeteroConv (ref: models/cadence.py:147-159)
@@ -272,6 +273,22 @@ int agnn_gated_bwd_dst_f32(const agnn_gated_t* g /* (host) */, const float* ds, 
                            float* dc, agnn_stream_t stream);
 int agnn_gated_bwd_src_f32(const agnn_gated_t* g /* (host) */, const float* ds, int64_t ld_ds, float* db,
                            float* dh, agnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Aggregation side of the in-tree RelEdgeConv (ref: models/core/gnn.py:99-105: m_ij = W_e [h_j || |h_i - h_j|] + b_e scattered
+ * with mean onto row i).  W_e is linear, so sum_j m_ij = W_e [S_i || D_i] + deg_i b_e with the two per-row aggregates
+ *     S_i = sum_{p in row i} h_col[p] ,    D_i = sum_{p in row i} |h_i - h_col[p]|
+ * computed here in one pass (either output may be NULL); the edge GEMM [E, 2F] x [2F, F] becomes a node GEMM.
+ * Backward, one launch per CSR direction, the second with accumulate = 1 onto the first's output:
+ *     by_col = 0 (the forward CSR):      out_r (+)= gd_r * sum_p sign(h_r - h_col[p])
+ *     by_col = 1 (the transposed CSR):   out_r (+)= sum_p [ sign(h_r - h_col[p]) * gd_col[p] + gs_col[p] ]
+ * (gd / gs: gradients of D / S, either may be NULL; sign(0) = 0 as torch.abs' backward.)  H % 4 == 0, H <= 1024.
+ * ------------------------------------------------------------------------------------------ */
+int agnn_absdiff_fwd_f32(const int32_t* rowptr, const int32_t* col, const float* h, int64_t ld, int64_t n_rows, int32_t H,
+                         float* out_s, float* out_d, int64_t ld_out, agnn_stream_t stream);
+int agnn_absdiff_bwd_f32(const int32_t* rowptr, const int32_t* col, const float* h, int64_t ld, int64_t n_rows, int32_t H,
+                         const float* gd, const float* gs, int64_t ld_g, int32_t by_col, int32_t accumulate, float* out,
+                         int64_t ld_out, agnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused [ReLU ->] LayerNorm [-> ReLU] [-> dropout] over the rows of x [n, H] (the element-wise chains between the
