@@ -436,6 +436,12 @@ class _HybridMixin:
             x_gnn, x_seq = _ForkInput.apply(x_in, batch_size, side)
             gnn_note = _FlushPoint.apply(x_gnn)
         side.wait_stream(main)
+        # x_in was allocated on the main stream and is READ on the side stream — in forward, and again in backward by the
+        # first recurrent layer's weight gradient (its saved input is a view of x_in).  Without this the allocator hands the
+        # block back to the main stream's pool the moment the last Python reference dies, while the side stream's kernels
+        # that read it are only queued: a main-stream allocation then overwrites it under them (seen as a wrong
+        # rnn.weight_ih_l0 gradient with FlatGradBuffer(views=True) + deferral, tests/test_gpu_step.py).
+        x_in.record_stream(side)
 
         set_home_stream(main)
         if x_seq is not None and LATE_SEQUENCE_BACKWARD:

@@ -99,7 +99,7 @@ class _GRULayer(torch.autograd.Function):
         # chain's own continuation a later-captured dependent) — the work goes to the main chain's flush, behind an event.
         if ctx.last_in_backward and off_chain and deferring(dy):
             defer(forked, dev)
-        elif not (off_chain and deferring(dy) and defer_home(weight_grads, dev)):
+        elif not (off_chain and deferring(dy) and defer_home(weight_grads, dev, (dgi, dgh, y, x2, hp, dw_ih, db_ih, dw_hh, db_hh))):
             forked()
         return dx, dw_ih.view(2, 3 * Hh, I), dw_hh, db_ih.view(2, 3 * Hh), db_hh, None, None
 

@@ -174,9 +174,11 @@ def set_home_stream(stream) -> None:
     _DEFER["home"] = stream
 
 
-def defer_home(fn, dev) -> bool:
+def defer_home(fn, dev, tensors=()) -> bool:
     """From a branch stream: hand optimizer-only work to the main chain's flush (it runs there behind an event recorded
-    now on the current stream).  False when there is no home stream, or the current stream is it."""
+    now on the current stream).  False when there is no home stream, or the current stream is it.  `tensors`: what `fn`
+    reads and writes — allocated on the branch's stream, used on the home stream: recorded there, so that the allocator does
+    not hand their blocks back to the branch's pool while the home stream's kernels are only queued."""
     home = _DEFER.get("home")
     cur = torch.cuda.current_stream(dev)
     if home is None or (home.device.index, home.cuda_stream) == (cur.device.index, cur.cuda_stream):
@@ -185,8 +187,12 @@ def defer_home(fn, dev) -> bool:
     ev.record(cur)
 
     def run():
-        torch.cuda.current_stream(dev).wait_event(ev)
+        here = torch.cuda.current_stream(dev)
+        here.wait_event(ev)
         fn()
+        for t in tensors:
+            if t is not None:
+                t.record_stream(here)
     defer_on(home, run)
     return True
 

@@ -11,18 +11,23 @@ import torch
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
-def seeded_fill_(module: torch.nn.Module, seed: int, scale: float = 0.08) -> None:
+def seeded_fill_(module: torch.nn.Module, seed: int, scale: float = 0.08, rename=None, norm_offset: float = 0.0) -> None:
     """Overwrite every parameter/buffer-free tensor of `module` deterministically from `seed`.
 
     Used for the large (H=256) fixtures whose weights are too big to commit: generator and
     test re-create identical weights from the seed.  Parameters are filled in
     `named_parameters()` order from one stream per parameter name (order independent).
+    `rename`: maps a parameter name to the name its stream is keyed by (two modules whose names differ by a prefix get
+    the same values); `norm_offset` is added to every 1-D `*.weight` (LayerNorm scales around 1 instead of around 0).
     """
     with torch.no_grad():
         for name, p in module.named_parameters():
+            name = rename(name) if rename is not None else name
             h = int.from_bytes(hashlib.sha256(name.encode()).digest()[:4], "little")
             g = torch.Generator().manual_seed((seed * 1000003 + h) % (2 ** 31))
             p.copy_(torch.randn(p.shape, generator=g, dtype=torch.float32) * scale)
+            if norm_offset and p.dim() == 1 and name.endswith(".weight"):
+                p.add_(norm_offset)
 
 
 def seeded_randn(seed: int, *shape: int) -> torch.Tensor:
@@ -59,3 +64,15 @@ def checksum(t: torch.Tensor) -> np.ndarray:
 
 def golden_path(name: str) -> str:
     return os.path.join(GOLDEN_DIR, name)
+
+
+def r3_graphs() -> dict:
+    """The synthetic batches of the round-3 wrapper fixtures (oracle/gen_golden_r3.py), rebuilt from seeds by generator and
+    tests alike: the graph generator is the build's own (analysisgnn_amd/synth.py), deterministic in its seed."""
+    from analysisgnn_amd.synth import make_batch, make_score_graph, merge_sampled, sample_hops
+    return {
+        "whole": make_batch(2, 80, first_seed=31),
+        "sampled": merge_sampled([sample_hops(make_score_graph(seed=sd, n_notes=160), 60, (5, 5), seed=sd, first_target=10)
+                                  for sd in (41, 42)]),
+        "hetero": make_batch(2, 80, first_seed=51, add_beats=True, add_measures=True, reverse_metrical_edges=True),
+    }

@@ -42,3 +42,37 @@ def assert_close(a, b, tol, what=""):
     scale = max(1.0, float(b.abs().max())) if b.numel() else 1.0
     err = float((a - b).abs().max()) if b.numel() else 0.0
     assert err <= tol * scale, f"{what}: max abs err {err:.3e} > {tol:.1e} * {scale:.3g}"
+
+
+def assert_close_rel(a, b, tol, what="", floor=1e-7):
+    """max |a - b| <= tol * max |b| (+ floor): the tolerance is relative to the tensor's OWN largest magnitude,
+    not to max(1, .) as `assert_close` — small-valued gradients are held to the same relative bound as O(1) logits."""
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    if not b.numel():
+        return
+    scale = float(b.abs().max())
+    err = float((a - b).abs().max())
+    assert err <= tol * scale + floor, f"{what}: max abs err {err:.3e} > {tol:.1e} * max|ref| {scale:.3g}"
+
+
+R3_CASES = ["r3_wrapper_hybrid_fusion", "r3_wrapper_hybrid_plain_sampled", "r3_wrapper_hybrid_jk_sum", "r3_wrapper_hgt_fusion",
+            "r3_wrapper_metrical_plain", "r3_wrapper_c2_h256", "r3_wrapper_c2_h256_fusion"]
+
+
+def r3_case(name):
+    """A round-3 wrapper fixture (oracle/gen_golden_r3.py: the reference's own TorchAnalysisGNN / MultiTaskLoss class source run
+    in float64) -> (npz, cfg dict, graph, inputs on CPU, labels): everything the generator fed the reference, rebuilt."""
+    from analysisgnn_amd.synth import torch_inputs
+    from oracle.testing import r3_graphs
+    z = load_golden(name)
+    H, OUT, L, fusion, use_jk, wloss, in_ch, seed, big = (int(v) for v in z["meta.cfg"])
+    cfg = dict(H=H, OUT=OUT, L=L, fusion=bool(fusion), use_jk=bool(use_jk), wloss=bool(wloss), in_ch=in_ch, seed=seed, big=bool(big),
+               enc=str(z["meta.encoder"]), tasks={str(t): int(c) for t, c in zip(z["meta.tasks"], z["meta.classes"])})
+    g = r3_graphs()[str(z["meta.graph"])]
+    I = torch_inputs(g, in_channels=in_ch, seed=seed + 3)
+    labels = torch.from_numpy(np.asarray(z["in.labels"]))
+    if not big:
+        assert np.array_equal(I["x_dict"]["note"].numpy(), z["in.x_note"]) and np.array_equal(I["pitch_spelling"].numpy(), z["in.pitch_spelling"])
+    return z, cfg, g, I, labels
