@@ -233,8 +233,14 @@ def fused_logit_fusion(proj_layers: nn.ModuleDict, transformer: nn.Module, fusio
     pm = [proj_layers[t] for t in tasks]
     K = pm[0][0].out_features
     N = logits.shape[0]
-    if not (logits.is_cuda and K in GPROJ_K and T <= _lib.MAX_SEG):
-        raise _lib.AgnnError(f"logit fusion: projection width {K} / {T} tasks not supported by the grouped kernels")
+    _lib.require_gpu(logits)
+    if not (K in GPROJ_K and T <= _lib.MAX_SEG):
+        # Widths the grouped kernels are not built for (out_channels // 2 outside {32, 64, 128}; more than MAX_SEG tasks): the
+        # same epilogue as per-task launches on the device — the reference's own loop (:552-565).  Correct, not tuned: the
+        # tuned shape is the reference's default (out_channels = 128, 21 tasks).
+        proj = [pm[i](logits[:, offs[i]:offs[i + 1]]) for i in range(T)]
+        enh = transformer(torch.stack(proj, dim=1))
+        return torch.cat([fusion_layers[t](enh[:, i]) for i, t in enumerate(tasks)], dim=1)
     Wp = torch.cat([m[0].weight.t() for m in pm], dim=0)                                 # [sum C, K]
     bp = cat_rows([m[0].bias for m in pm])                                                # [T*K]
     a = grouped_in_projection(logits, Wp, offs, K) + bp

@@ -39,6 +39,7 @@ TASK_DICT = {  # train/train_analysisgnn.py:22-45 (duplicate key "organ_point" c
 }
 C5_TASKS = {"cadence": 4, "localkey": 50, "romanNumeral": 185}
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
+MFMA_F32_PEAK = 157.3e12   # FLOP/s, dense fp32 MFMA (v_mfma_f32_32x32x2_f32; MI355X_MICROARCH.md)
 N_SUB, N_NOTES, IN_CH, H, OUT, LAYERS = 32, 500, 25, 256, 128, 3
 
 WORKLOADS = {
@@ -142,6 +143,53 @@ def build_workload(name: str, rank: int, world: int, n_sub: int = N_SUB):
     if name == "c5":
         return make_batch(n_sub, N_NOTES, seeds=seeds), "metricalgnn", 512, 4, C5_TASKS
     raise ValueError(name)
+
+
+def algorithmic_flops(enc, I, hid, layers, tasks):
+    """ALGORITHMIC matrix FLOPs of one training step (what a dense-algebra implementation of the reference's layers cannot
+    avoid: 2 m k n per product, every product once forward and twice backward — dX and dW — except the input layers' dX,
+    their inputs being data).  Aggregations, norms, activations, the objective and the optimizer are byte work and are not
+    counted.  SAGE layers follow the build's formulation (R neighbour products + ONE root product per layer,
+    the per-relation root weights pre-summed; a trimmed layer that keeps no edge is its root product alone); rows per layer
+    follow PyG's trim_to_layer.  -> (total, breakdown dict)."""
+    from analysisgnn_amd.encoders import TrimPlan
+    mm = lambda m, k, n: 2.0 * m * k * n                                           # noqa: E731
+    n_all = {t: int(v.shape[0]) for t, v in I["x_dict"].items()}
+    B = int(I["batch_size"])
+    plan = TrimPlan(layers, I["x_dict"], I["edge_index_dict"], I["neighbor_mask_node"], I["neighbor_mask_edge"])
+    ets = list(I["edge_index_dict"].keys())
+    T = len(tasks)
+    fwd, no_dx = {}, 0.0
+    first = sum(mm(n, IN_CH + (128 if t == "note" else 0), hid) for t, n in n_all.items())
+    fwd["input MLPs (project_dict)"] = first + sum(mm(n, hid, hid) for n in n_all.values())
+    no_dx += first
+    stack = 0.0
+    for layer in range(layers):
+        nk, ek = plan.n_keep[layer], plan.e_keep[layer]
+        live = [et for et in ets if ek[et] is None or ek[et] > 0]
+        if enc == "hgt":
+            D, heads = hid // 4, 4
+            n_src = plan.n_keep[layer - 1] if layer > 0 else n_all
+            for t in n_all:
+                stack += mm(n_src[t] if any(et[0] == t for et in live) else nk[t], hid, 3 * hid) + mm(nk[t], hid, hid)   # kqv, out_lin
+            for et in live:
+                stack += 2 * heads * mm(n_src[et[0]], D, D)                          # k_rel and v_rel: one D x D matrix per head
+        else:
+            for d in n_all:
+                r = sum(1 for et in live if et[2] == d)
+                if r or any(et[2] == d for et in ets):
+                    stack += mm(nk[d], (r + 1) * hid, hid)
+    fwd["GNN stack projections"] = stack
+    if enc in ("hybridgnn", "hgt"):
+        hh = hid // 2
+        fwd["sequence branch (GRU input projections, recurrences, MLP, cat_proj)"] = (
+            2 * mm(B, hid, 6 * hh) + 2 * 2 * B * 2.0 * 3 * hh * hh + 2 * mm(B, hid, hid) + mm(B, 2 * hid, hid))
+    else:
+        fwd["encoder output MLP"] = 2 * mm(B, hid, hid)
+    fwd["project_enc"] = mm(B, 2 * hid, hid) + mm(B, hid, OUT) + mm(B, OUT, OUT)
+    fwd["task heads"] = mm(B, OUT, T * (OUT // 2)) + sum(mm(B, OUT // 2, c) for c in tasks.values())
+    total = 3.0 * sum(fwd.values()) - no_dx
+    return total, {k: 3.0 * v for k, v in fwd.items()}
 
 
 def reference_objective(logits, labels, feat, params):
@@ -304,6 +352,11 @@ def main():
     # refill; the graphs still rebuild the CSR from the COO edge lists on every replay.
     graphs = None
     loss_ref = [None]
+    graph_mode = "eager (--no-graph)"
+    # With a process group in the process the NCCL watchdog thread issues HIP calls of its own; in the default (global) capture
+    # error mode any such call from another thread invalidates a capture in progress.  thread_local confines the check to the
+    # capturing thread (what torch's own DDP + CUDA-graph recipes use).  One-rank runs keep the stricter default.
+    cap_mode = "thread_local" if world > 1 else "global"
     if not args.no_graph:
         try:
             side = torch.cuda.Stream(device=dev)
@@ -325,7 +378,7 @@ def main():
             for late in variants:
                 _enc.LATE_SEQUENCE_BACKWARD = late
                 g1 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1):
+                with torch.cuda.graph(g1, capture_error_mode=cap_mode):
                     loss_v = fwd_bwd()
                     if dot:
                         _dump_capture_dot(dot, dev)
@@ -345,12 +398,14 @@ def main():
             if rank == 0 and len(variants) > 1:
                 print(f"[bench] backward schedule: sequence branch {'behind a late node' if schedule_late else 'in autograd order'}",
                       file=sys.stderr)
-            with torch.cuda.graph(g2):
+            with torch.cuda.graph(g2, capture_error_mode=cap_mode):
                 update()
             graphs = (g1, g2)
-        except Exception as e:                                  # capture refused: run eagerly, say so in the JSON
+            graph_mode = f"hipGraph replay (capture_error_mode={cap_mode})"
+        except Exception as e:                                  # capture refused: run eagerly — a HOST-BOUND number, flagged at top level
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graphs = None
+            graph_mode = f"eager-fallback: {type(e).__name__}: {str(e)[:200]}"
             torch.cuda.synchronize(dev)
 
     def step():
@@ -412,9 +467,12 @@ def main():
             "metric": METRICS[args.workload], "value": nodes / dt, "unit": "subgraph-nodes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # how the step's launches were issued: "hipGraph replay ..." or "eager-fallback: <why the capture failed>" (then the
+            # figure is bound by the host's launch rate, not by the GPU — do not read it as the step's speed)
+            "graph": graph_mode,
             "config": {"workload": WORKLOADS[args.workload] + f"; {g.num_nodes['note']} notes, {e_tot} edges per GPU; train step = fwd + "
                                    f"objective ({args.mt_strategy}) + bwd + allreduce + clip + AdamW, CSR rebuilt every step; "
-                                   + ("hipGraph replay" if graphs is not None else "eager launches"),
+                                   + ("hipGraph replay" if graphs is not None else "EAGER launches (see \"graph\")"),
                        "workload_id": args.workload, "per_gpu_subgraphs": N_SUB, "target_notes_per_subgraph": N_NOTES,
                        "objective": args.mt_strategy,
                        "sharding": ("every rank draws its own windows from the replicated corpus" if args.workload == "c2d"
@@ -422,18 +480,24 @@ def main():
                        "parallelism": f"dp{world}"},
             "roofline": roof,
         }
+        # whole-step efficiency as a reported number: algorithmic matrix FLOPs of the step / step time / fp32-MFMA peak
+        fl, parts = algorithmic_flops(enc, I, hid, layers, tasks)
+        out["step_flops_alg"] = fl
+        out["mfma_frac"] = fl / (dt / args.steps) / MFMA_F32_PEAK
+        out["step_flops_breakdown"] = {k: round(v / 1e9, 3) for k, v in parts.items()}     # GFLOP per step (fwd + bwd)
         if world == 1 and args.workload == "c2s" and not args.no_other:
             # secondary figures, each a child process with the same steps: "c2" = continuity with round 1's line (whole graphs,
             # nothing trimmed); "c2d" = the same training step with the batch sampled and gathered ON THE DEVICE inside it
             out["other_workloads"] = {}
-            for wl in ("c2", "c2d"):
+            for wl in ("c2", "c2d", "c3", "c5"):
                 try:
                     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", wl, "--no-cpu-baseline", "--steps",
                                         str(args.steps), "--warmup", str(args.warmup), "--mt-strategy", args.mt_strategy],
                                        capture_output=True, text=True, timeout=300)
                     o = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-                    out["other_workloads"][wl] = {"value": o["value"], "ms_per_step": o["ms_per_step"], "workload": o["config"]["workload"],
-                                                  "roofline": o["roofline"]}
+                    out["other_workloads"][wl] = {"metric": o["metric"], "value": o["value"], "ms_per_step": o["ms_per_step"],
+                                                  "workload": o["config"]["workload"], "graph": o["graph"], "roofline": o["roofline"],
+                                                  "step_flops_alg": o["step_flops_alg"], "mfma_frac": o["mfma_frac"]}
                 except Exception as e:                              # secondary figures only
                     out["other_workloads"][wl] = f"not measured ({type(e).__name__})"
         if world == 1 and not args.no_cpu_baseline:

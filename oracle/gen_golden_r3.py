@@ -37,7 +37,7 @@ sys.dont_write_bytecode = True
 
 from oracle import encoders_ref as E  # noqa: E402
 from oracle import scatter_ref  # noqa: E402
-from oracle.testing import GOLDEN_DIR, checksum, r3_graphs, seeded_fill_  # noqa: E402
+from oracle.testing import GOLDEN_DIR, ReluTap, checksum, r3_graphs, seeded_fill_  # noqa: E402
 from analysisgnn_amd.synth import torch_inputs  # noqa: E402
 
 REF_ANALYSIS = "/root/reference/analysisgnn/models/analysis.py"
@@ -116,6 +116,26 @@ def total_loss(model, clf_loss, I, labels, tasks, lambda_featl=0.1):
 
 
 def make_case(ns, name, enc, gname, tasks, H, OUT, L, fusion, use_jk, seed, wloss=True, big=False, in_ch=25):
+    """A ReLU's derivative at 0 is a convention and within fp32 rounding of 0 it is a coin toss: a gradient fixture that sits on
+    such a point pins nothing (one flipped derivative among 160 notes moves every encoder gradient by ~2e-4 — measured, see
+    profiles/r03_parity_notes.md).  So the fixture's float64 run records every ReLU input and the weights are re-drawn
+    (seed + 1000, ...) until none lies within 3e-6 of its call's largest magnitude (~15x the fp32 path's absolute error there); the margin reached is stored
+    (`meta.relu_margin`).  What flips DO to the HIP path's gradients is measured where the oracle can be re-run:
+    tests/test_gpu_c5.py, four seeds, flips counted."""
+    for attempt in range(80):
+        rec, margin, risk = _run_case(ns, enc, gname, tasks, H, OUT, L, fusion, use_jk, seed + 1000 * attempt, wloss, big, in_ch)
+        if risk == 0:
+            break
+        print(f"  {name}: seed {seed + 1000 * attempt}: {risk} ReLU inputs within 3e-6 of the kink, re-drawing")
+    assert risk == 0
+    rec["meta.relu_margin"] = np.array(margin)
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print(f"  wrote {name}.npz ({os.path.getsize(path) / 1024:.1f} KiB)  seed {int(rec['meta.cfg'][7])}  total loss {float(rec['loss.total']):.6f}  "
+          f"ReLU margin {margin:.1e}")
+
+
+def _run_case(ns, enc, gname, tasks, H, OUT, L, fusion, use_jk, seed, wloss, big, in_ch):
     torch.manual_seed(seed)
     graph = r3_graphs()[gname]
     md = graph.metadata()
@@ -142,7 +162,8 @@ def make_case(ns, name, enc, gname, tasks, H, OUT, L, fusion, use_jk, seed, wlos
     gl = torch.Generator().manual_seed(seed + 4)
     labels = torch.stack([torch.randint(0, c, (bs,), generator=gl) for c in tasks.values()])
     labels[torch.rand(labels.shape, generator=gl) < 0.15] = -1                       # ignore_index rows (analysis.py:883)
-    x, logits, per_task, total = total_loss(model, clf_loss, I, labels, list(tasks))
+    with ReluTap() as tap:
+        x, logits, per_task, total = total_loss(model, clf_loss, I, labels, list(tasks))
     total.backward()
     rec = {"meta.tasks": np.array(list(tasks)), "meta.classes": np.array(list(tasks.values()), dtype=np.int64),
            "meta.cfg": np.array([H, OUT, L, int(fusion), int(use_jk), int(wloss), in_ch, seed, int(big)], dtype=np.int64),
@@ -178,9 +199,7 @@ def make_case(ns, name, enc, gname, tasks, H, OUT, L, fusion, use_jk, seed, wlos
         for k, p in model.named_parameters():
             if p.grad is not None:
                 rec["gw." + build_names(k)] = p.grad.float().numpy()     # fp32 storage of the float64 result: 6e-8 relative
-    path = os.path.join(GOLDEN_DIR, name + ".npz")
-    np.savez_compressed(path, **rec)
-    print(f"  wrote {name}.npz ({os.path.getsize(path) / 1024:.1f} KiB)  total loss {total.item():.6f}")
+    return rec, tap.margin(), tap.at_risk(3e-6)
 
 
 SMALL_TASKS = {"cadence": 4, "localkey": 50, "romanNumeral": 185, "hrythm": 2}
@@ -188,6 +207,14 @@ SMALL_TASKS = {"cadence": 4, "localkey": 50, "romanNumeral": 185, "hrythm": 2}
 
 
 def main():
+    only = sys.argv[1:]
+    if only:                     # regenerate the named cases only
+        global make_case
+        _mk = make_case
+
+        def make_case(ns, name, *a, **k):
+            if name in only:
+                _mk(ns, name, *a, **k)
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     torch.set_num_threads(4)
     ns = reference_namespace()
@@ -199,7 +226,7 @@ def main():
               False, False, 105)
     import bench
     make_case(ns, "r3_wrapper_c2_h256", "hybridgnn", "sampled", dict(bench.TASK_DICT), 256, 128, 3, False, False, 106, big=True)
-    make_case(ns, "r3_wrapper_c2_h256_fusion", "hybridgnn", "whole", dict(bench.TASK_DICT), 256, 128, 3, True, False, 107, big=True)
+    make_case(ns, "r3_wrapper_c2_h256_fusion", "hybridgnn", "one", dict(bench.TASK_DICT), 256, 128, 3, True, False, 107, big=True)
 
 
 if __name__ == "__main__":

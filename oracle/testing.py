@@ -30,6 +30,37 @@ def seeded_fill_(module: torch.nn.Module, seed: int, scale: float = 0.08, rename
                 p.add_(norm_offset)
 
 
+class ReluTap:
+    """Records the input of every F.relu call while active (nn.ReLU and the CPU oracle both end there): the only points
+    where the model is not differentiable (dropout = 0).  `margin()` = the smallest |input| relative to the largest of its
+    call; `at_risk(delta)` = how many inputs lie within delta * max|input| of the kink — an fp32 evaluation (absolute error
+    ~1e-6 of the largest term) may put those on the other side, which flips a derivative and moves gradients by far more
+    than rounding does."""
+
+    def __init__(self):
+        self.inputs = []
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self._F, self._orig = F, F.relu
+
+        def relu(x, *a, **k):
+            self.inputs.append(x.detach())
+            return self._orig(x, *a, **k)
+        F.relu = relu
+        return self
+
+    def __exit__(self, *exc):
+        self._F.relu = self._orig
+        return False
+
+    def margin(self) -> float:
+        return min(float(x.abs().min() / x.abs().max()) for x in self.inputs if x.numel())
+
+    def at_risk(self, delta: float = 2e-5) -> int:
+        return sum(int((x.abs() < delta * x.abs().max()).sum()) for x in self.inputs if x.numel())
+
+
 def seeded_randn(seed: int, *shape: int) -> torch.Tensor:
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g, dtype=torch.float32)
@@ -75,4 +106,5 @@ def r3_graphs() -> dict:
         "sampled": merge_sampled([sample_hops(make_score_graph(seed=sd, n_notes=160), 60, (5, 5), seed=sd, first_target=10)
                                   for sd in (41, 42)]),
         "hetero": make_batch(2, 80, first_seed=51, add_beats=True, add_measures=True, reverse_metrical_edges=True),
+        "one": make_batch(1, 64, first_seed=61),
     }

@@ -289,3 +289,40 @@ def test_existing_grads_with_deferred_and_overlapped_weight_grads(mode):
         dp.defer_weight_grads(False)
         dp.enable_wgrad_overlap(False)
         graph.index_cache_enabled = was
+
+
+def test_nested_wgrad_stream_inside_a_capture():
+    """Round 2's capture crash (c6b44df): a `wgrad_stream` entered while ALREADY on the weight-gradient stream made that
+    stream wait for itself, and hipStreamEndCapture crashed.  The guard (linear.wgrad_stream.__enter__: no wait when the current
+    stream is the weight-gradient stream) is pinned here: nested entry inside a capture, replayed twice."""
+    from analysisgnn_amd import dp, linear
+    dev = torch.device("cuda", 0)
+    x = torch.arange(1024, dtype=torch.float32, device=dev)
+    out = torch.zeros_like(x)
+    dp.enable_wgrad_overlap(True, "all")
+    try:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                       # warm-up outside the capture (allocations, stream creation)
+            with linear.wgrad_stream(dev, x):
+                with linear.wgrad_stream(dev, x):
+                    out.copy_(x)
+            linear.join_wgrad()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
+            with linear.wgrad_stream(dev, x) as outer:
+                assert outer.on
+                y = x * 2.0
+                with linear.wgrad_stream(dev, y) as inner:  # already on the stream
+                    assert inner.on
+                    out.copy_(y + 1.0)
+            linear.join_wgrad()
+        for _ in range(2):
+            out.zero_()
+            cg.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, x * 2.0 + 1.0)
+    finally:
+        dp.enable_wgrad_overlap(False)
