@@ -62,17 +62,17 @@ def test_weight_gradient_at_c5_projection_sizes(out_f, in_f):
     assert_close(db, ref_b, 1e-4, "db")
 
 
-def _oracle_run(P, g, I, L, dtype):
+def _oracle_run(P, g, I, L, dtype, keep_graph=False):
     from oracle import encoders_ref as E
+    from oracle.testing import ReluTap
     Pd = {k: (v.detach().to(dtype).requires_grad_(True) if v.is_floating_point() else v) for k, v in P.items()}
     xd = {k: v.to(dtype) for k, v in I["x_dict"].items()}
-    from oracle.testing import ReluTap
-    with ReluTap() as tap:
+    with ReluTap(keep_graph=keep_graph) as tap:
         x = E.analysis_encode(Pd, "metricalgnn", g.metadata(), L, I["pitch_spelling"], I["key_signature"], xd, I["edge_index_dict"],
                               I["batch_dict"], I["batch_size"], I["neighbor_mask_node"], I["neighbor_mask_edge"])
         ref = E.analysis_logits(Pd, x, list(C5_TASKS))
-    sum((v ** 2).mean() for v in ref.values()).backward()
-    return ref, Pd, tap
+    loss = sum((v ** 2).mean() for v in ref.values())
+    return ref, Pd, tap, loss
 
 
 @pytest.mark.parametrize("seed", [7, 1, 2, 3])
@@ -81,18 +81,17 @@ def test_c5_model_on_sampled_subgraphs_matches_float64_cpu_path(seed):
     per-hop counts passed: every layer trimmed): forward logits and all parameter gradients against a FLOAT64 run of
     oracle/encoders_ref.py, over four weight seeds (round 2 ran ONE seed, picked because no ReLU input sat within fp32
     rounding of zero — VERDICT r2 weak #2).
-    An input that close to the kink gets its derivative from whichever side the fp32 rounding of THIS evaluation order puts
-    it on; one flipped derivative changes one row of an activation gradient by its full value and every weight gradient
-    upstream by ~1e-4 relative (profiles/r03_parity_notes.md).  Here that is measured instead of avoided:
+    A ReLU input that close to the kink gets its derivative from whichever side the fp32 rounding of THIS evaluation order
+    puts it on; one flipped derivative moves a whole row of an activation gradient and every weight gradient upstream by
+    1e-4 ... 1e-3 relative (profiles/r03_parity_notes.md).  Here that is ATTRIBUTED, not avoided and not tolerated blindly:
       * logits: always within 1e-4 of float64;
-      * the float64 run records all 6.9 M ReLU inputs; those within 3e-6 of their call's largest magnitude are AT RISK
-        (the fp32 paths' absolute error there is ~2e-7 of it);
-      * a gradient tensor within 1e-4 * max(1, |ref|max) of float64 passes outright.  One beyond it is accepted only as the
-        footprint of flips: at-risk inputs exist, its error in the Frobenius norm stays below 3e-4 of the reference's (a
-        few rows moved, no general loss of accuracy) and its largest deviation below 1e-3.  Every such tensor is printed
-        with both numbers, next to the same numbers for the fp32 run of the CPU oracle (another summation order, its own flips)."""
+      * gradients: within 1e-4 * max(1, |ref|max) of float64 — directly, or after removing the exactly computed effect of
+        flipped ReLU derivatives (oracle.testing.explain_by_relu_flips: one float64 backward pass per ReLU input near the
+        kink gives the direction its flip moves the gradients in; the deviation over ALL parameters at once must be a 0/1
+        combination of those directions, every residual back inside the 1e-4 bound).  The flips found are printed."""
     from analysisgnn_amd.models import TorchAnalysisGNN
     from analysisgnn_amd.synth import make_sampled_batch, torch_inputs
+    from oracle.testing import explain_by_relu_flips
     g = make_sampled_batch(4, 500, (5, 5, 5), first_seed=40)
     H, L = 512, 4
     torch.manual_seed(seed)
@@ -102,11 +101,7 @@ def test_c5_model_on_sampled_subgraphs_matches_float64_cpu_path(seed):
     m = m.to(DEV)
     I = torch_inputs(g, in_channels=25, seed=5)
     assert I["batch_size"] == 2000 and len(I["neighbor_mask_node"]["note"]) == 4
-    ref64, P64, tap64 = _oracle_run(P, g, I, L, torch.float64)
-    ref32, P32, tap32 = _oracle_run(P, g, I, L, torch.float32)
-    at_risk = tap64.at_risk(3e-6)
-    cpu_flips = sum(int(((a > 0) != (b > 0)).sum()) for a, b in zip(tap64.inputs, tap32.inputs))
-    n_relu = sum(a.numel() for a in tap64.inputs)
+    ref64, P64, tap64, loss64 = _oracle_run(P, g, I, L, torch.float64, keep_graph=True)
     J = {k: ({kk: vv.to(DEV) for kk, vv in v.items()} if isinstance(v, dict) and v and isinstance(next(iter(v.values())), torch.Tensor)
              else (v.to(DEV) if isinstance(v, torch.Tensor) else v)) for k, v in I.items()}
     out = m(J["pitch_spelling"], J["key_signature"], J["x_dict"], J["edge_index_dict"], J["batch_dict"], J["batch_size"],
@@ -115,25 +110,28 @@ def test_c5_model_on_sampled_subgraphs_matches_float64_cpu_path(seed):
         assert out[t].shape == (2000, C5_TASKS[t])
         assert_close(out[t], ref64[t], 1e-4, f"logits[{t}]")
     sum((v ** 2).mean() for v in out.values()).backward()
-    flagged, n = [], 0
-    for name, p in m.named_parameters():
-        g64 = P64[name].grad
-        if g64 is None:
-            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+    names = [k for k, _ in m.named_parameters()]
+    hip = [p.grad if p.grad is not None else torch.zeros_like(p) for _, p in m.named_parameters()]
+    plist = [P64[k] for k in names]
+    g64 = torch.autograd.grad(loss64, plist, retain_graph=True, allow_unused=True)
+    bound = lambda ref: 1e-4 * max(1.0, float(ref.abs().max()))                      # noqa: E731
+    beyond = []
+    for k, gh, gr in zip(names, hip, g64):
+        if gr is None:
+            assert float(gh.abs().max()) == 0.0, k
             continue
-        assert p.grad is not None, f"{name}: no gradient on the HIP path"
-        n += 1
-        scale = max(1.0, float(g64.abs().max()))
-        d_hip = p.grad.detach().cpu().double() - g64
-        err_hip = float(d_hip.abs().max())
-        if err_hip <= 1e-4 * scale:
-            continue
-        fro_hip = float(d_hip.norm() / g64.norm())
-        d_cpu = P32[name].grad.double() - g64
-        flagged.append((name, f"max {err_hip:.1e} fro {fro_hip:.1e}", f"fp32 CPU: max {float(d_cpu.abs().max()):.1e} fro {float(d_cpu.norm() / g64.norm()):.1e}"))
-        assert at_risk > 0, f"grad {name}: {err_hip:.2e} > 1e-4 * {scale:.3g} with no ReLU input near the kink"
-        assert fro_hip <= 3e-4 and err_hip <= 1e-3 * scale, f"grad {name}: max {err_hip:.2e}, Frobenius {fro_hip:.2e} of the reference"
-    assert n > 20
-    print(f"[c5 seed {seed}] ReLU inputs: {n_relu}, at risk (|x| < 3e-6 max|x|): {at_risk}, flipped between the fp32 and float64 CPU "
-          f"runs: {cpu_flips}; gradient tensors beyond 1e-4 (of {n}): {flagged}")
-    assert len(flagged) <= n // 4, flagged
+        err = float((gh.detach().cpu().double() - gr).abs().max())
+        if err > bound(gr):
+            beyond.append((k, f"{err:.1e}"))
+    n_relu = sum(x.numel() for x in tap64.inputs)
+    if not beyond:
+        print(f"[c5 seed {seed}] all {sum(t is not None for t in g64)} gradient tensors within 1e-4 of float64 "
+              f"({n_relu} ReLU inputs, {tap64.at_risk(3e-6)} within 3e-6 of the kink, none flipped on the HIP path)")
+        return
+    rep = explain_by_relu_flips(tap64, loss64, plist, hip, bound)
+    print(f"[c5 seed {seed}] {len(beyond)} gradient tensors beyond 1e-4 of float64 (e.g. {beyond[:3]}); {n_relu} ReLU inputs, "
+          f"{rep['n_candidates']} candidates near the kink examined, flipped on the HIP path: {rep['flips']} "
+          f"(fitted coefficients other than 0: {[c for c in rep['coeffs'] if abs(c) > 0.02]}); worst residual after removing them: "
+          f"{rep['worst'][1]:.1e} (bound {rep['worst'][2]:.1e}) in {names[rep['worst'][0]]}")
+    assert rep["ok"], f"gradient deviation is not explained by flipped ReLU derivatives: {rep['worst']}, coefficients {rep['coeffs']}"
+    assert 0 < len(rep["flips"]) <= 8, rep["flips"]
