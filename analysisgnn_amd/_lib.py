@@ -9,7 +9,6 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# AGNN_LIB: another build of the same C-ABI (scripts/csr_memset_probe.py loads the memset-probe variant); normally unset
 LIB_PATH = os.path.join(_HERE, "libagnn_hip.so")
 MAX_SEG = 32
 
@@ -106,6 +105,8 @@ SIGNATURES = {
     "agnn_sampler_num_nodes": (C.c_int64, [C.POINTER(Sampler)]),
     "agnn_sampler_edge_capacity": (C.c_int64, [C.POINTER(Sampler)]),
     "agnn_sample_hops": (C.c_int, [C.POINTER(Sampler), C.c_void_p]),
+    "agnn_sample_members": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
+                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "agnn_gather_rows_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "agnn_gather_i64": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "agnn_relt_fwd_f32": (C.c_int, [C.c_int, C.POINTER(ReltItem), C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),

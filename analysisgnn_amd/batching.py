@@ -8,7 +8,9 @@ Static shapes are what lets the WHOLE step (sampling, feature gather, CSR build,
 once and replayed with a different batch every time: hop blocks are padded to a capacity, padding nodes carry no features
 and no edges, padding edge slots hold (-1, -1) and are dropped by the CSR build, and `num_sampled_nodes/edges` are the
 capacities, so `trim_to_layer` trims whole padded blocks.  Only the 32 window starts cross the PCIe bus per step.
-Note-only graphs (the relations among notes), as `synth.sample_hops`.  No CPU path."""
+Neighbour sampling runs over the relations among notes (as `synth.sample_hops`); when the scores carry metrical nodes
+(beats, measures — the reference's default, data/datamodules/analysis.py:213-225) a second launch per metrical type
+(`agnn_sample_members`) adds each subgraph's beats / measures and the membership edges of its notes.  No CPU path."""
 from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -56,6 +58,22 @@ class ScoreStore:
             self._keep += [s_t, d_t]
             specs.append(SegSpec(row=d_t, col=s_t, n_rows=n))
         self.csr = build_csr(specs)                          # rows = destination note, col = source note
+        # metrical node types: per note the GLOBAL id of its beat / measure (scores concatenated), and synthetic features
+        self.group_types: List[str] = [t for t in ("beat", "measure") if ("note", "connects", t) in graphs[0].edge_index]
+        self.group_of: Dict[str, torch.Tensor] = {}
+        self.group_x: Dict[str, torch.Tensor] = {}
+        for t in self.group_types:
+            ids, off = [], 0
+            for g in graphs:
+                e = g.edge_index[("note", "connects", t)]
+                if not np.array_equal(e[0], np.arange(g.num_nodes["note"])) or np.any(np.diff(e[1]) < 0):
+                    raise _lib.AgnnError(f"ScoreStore: ('note', 'connects', '{t}') must list every note once, groups non-decreasing")
+                ids.append(e[1] + off)
+                off += int(g.num_nodes[t])
+            self.group_of[t] = torch.from_numpy(np.concatenate(ids).astype(np.int32)).to(dev)
+            xg = torch.zeros(off, width)
+            xg[:, :in_channels] = torch.randn(off, in_channels, generator=gen)
+            self.group_x[t] = xg.to(dev)
 
     def random_windows(self, n_sub: int, n_targets: int, rng: np.random.Generator) -> np.ndarray:
         """What the loader's sampler decides on the host: `n_sub` (score, first target) pairs -> global ids, int32."""
@@ -71,7 +89,7 @@ class DeviceSampler:
     graph replays it); `batch` is the dict `TorchAnalysisGNN.encode` consumes (the keys of `synth.torch_inputs`)."""
 
     def __init__(self, store: ScoreStore, n_sub: int, n_targets: int = 500, num_neighbors: Sequence[int] = (5, 5),
-                 capacity: Sequence[int] = (64, 64), seed: int = 0):
+                 capacity: Sequence[int] = (64, 64), seed: int = 0, group_capacity: Optional[Dict[str, int]] = None):
         if len(capacity) != len(num_neighbors):
             raise ValueError("one capacity per hop")
         self.store, self.n_sub, self.n_targets = store, int(n_sub), int(n_targets)
@@ -115,8 +133,25 @@ class DeviceSampler:
         self.batch_note.agnn_target_lengths = [T] * B
         self.x = torch.empty((self.num_nodes, store.x.shape[1]), dtype=torch.float32, device=dev)
         self.attrs = torch.empty((store.attrs.shape[0], self.num_nodes), dtype=torch.int64, device=dev)
+        # metrical node types: one static block of `group_capacity[t]` slots per subgraph (all hop 0: never trimmed), one
+        # membership edge slot per batch note (trimmed with its note's hop block)
+        self.group_cap = {t: int((group_capacity or {}).get(t, {"beat": 160, "measure": 48}[t])) for t in store.group_types}
+        self.group_gid, self.group_x = {}, {}
+        x_dict = {"note": self.x[:, :store.in_channels]}
+        batch_dict = {"note": self.batch_note}
+        self._cap_arr = (_lib.C.c_int32 * max(len(self.cap), 1))(*self.cap)
+        for t in store.group_types:
+            cg = self.group_cap[t]
+            et = ("note", "connects", t)
+            self.group_gid[t] = torch.empty(B * cg, dtype=torch.int32, device=dev)
+            self.edges[et] = torch.empty((2, self.num_nodes), dtype=torch.int64, device=dev)
+            self.group_x[t] = torch.empty((B * cg, store.group_x[t].shape[1]), dtype=torch.float32, device=dev)
+            self.num_sampled_nodes[t] = [B * cg] + [0] * len(self.cap)
+            self.num_sampled_edges[et] = [B * T + (B * self.cap[0] if self.cap else 0)] + [B * c for c in self.cap[1:]]
+            x_dict[t] = self.group_x[t][:, :store.in_channels]
+            batch_dict[t] = torch.from_numpy(np.repeat(np.arange(B), cg).astype(np.int64)).to(dev)
         self.batch = dict(
-            x_dict={"note": self.x[:, :store.in_channels]}, edge_index_dict=self.edges, batch_dict={"note": self.batch_note},
+            x_dict=x_dict, edge_index_dict=self.edges, batch_dict=batch_dict,
             pitch_spelling=self.attrs[0], key_signature=self.attrs[1], batch_size=self.batch_size,
             neighbor_mask_node=self.num_sampled_nodes, neighbor_mask_edge=self.num_sampled_edges,
             labels={t: self.attrs[2 + i, :self.batch_size] for i, t in enumerate(store.tasks)},
@@ -141,6 +176,11 @@ class DeviceSampler:
         ev.record(torch.cuda.current_stream(self.store.device))
         self._ring_ev[k] = ev
 
+    def metadata(self):
+        """(node types, edge types) of the batches this sampler writes — what the model constructors take."""
+        return (["note"] + list(self.store.group_types),
+                list(self.store.edge_types) + [("note", "connects", t) for t in self.store.group_types])
+
     def dropped(self) -> int:
         """Sources cut by the hop capacities since this sampler was created (synchronises; a statistic, not an error)."""
         return int(self.drops.item())
@@ -157,4 +197,12 @@ class DeviceSampler:
                                             self.x.data_ptr(), self.x.stride(0), st), "agnn_gather_rows_f32")
         _lib.check(lib.agnn_gather_i64(s.attrs.data_ptr(), s.attrs.stride(0), self.node_gid.data_ptr(), self.num_nodes, s.attrs.shape[0], 0,
                                        self.attrs.data_ptr(), self.attrs.stride(0), st), "agnn_gather_i64")
+        for t in s.group_types:          # + two launches per metrical type: members, their feature rows
+            cg = self.group_cap[t]
+            _lib.check(lib.agnn_sample_members(self.node_gid.data_ptr(), self.num_nodes, s.group_of[t].data_ptr(), self.win_start.data_ptr(),
+                                               self.n_sub, self.n_targets, len(self.cap), self._cap_arr, cg, self.group_gid[t].data_ptr(),
+                                               self.edges[("note", "connects", t)].data_ptr(), self.drops.data_ptr(), st), "agnn_sample_members")
+            gx = s.group_x[t]
+            _lib.check(lib.agnn_gather_rows_f32(gx.data_ptr(), gx.stride(0), self.group_gid[t].data_ptr(), self.n_sub * cg, gx.shape[1],
+                                                self.group_x[t].data_ptr(), self.group_x[t].stride(0), st), "agnn_gather_rows_f32")
         return self.batch

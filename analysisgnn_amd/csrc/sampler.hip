@@ -228,6 +228,59 @@ __global__ __launch_bounds__(kThreads) void k_sample_hops(SamplerArgs A) {
   if (tid == 0 && n_over > 0 && c.status != nullptr) atomicAdd(c.status, n_over);      // an error: the batch is incomplete
 }
 
+// Membership of the batch's notes in the metrical nodes (beats, measures) of their subgraph — agnn_sample_members.
+// Notes are sorted by onset, so the groups a window's target notes belong to form ONE contiguous id range
+// [group_of[w], group_of[w + T - 1]]: no set, no sort.  Thread i: group slot i (i < n_sub * cap_g) and note slot i (i < n_nodes).
+struct MemberArgs {
+  const int32_t* node_gid;
+  const int32_t* group_of;
+  const int32_t* win_start;
+  int32_t* group_gid;
+  int64_t* edges;
+  int32_t* drops;
+  int64_t n_nodes;
+  int32_t n_sub, n_targets, n_hops, cap_g;
+  int32_t cap[AGNN_SAMPLER_MAX_HOPS];
+};
+
+__global__ __launch_bounds__(256) void k_sample_members(MemberArgs a) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (idx < static_cast<int64_t>(a.n_sub) * a.cap_g) {
+    const int s = static_cast<int>(idx / a.cap_g), j = static_cast<int>(idx - static_cast<int64_t>(s) * a.cap_g);
+    const int w = a.win_start[s];
+    const int gmin = a.group_of[w], gmax = a.group_of[w + a.n_targets - 1];
+    a.group_gid[idx] = gmin + j <= gmax ? gmin + j : -1;
+    if (j == 0 && gmax - gmin + 1 > a.cap_g && a.drops != nullptr) atomicAdd(a.drops, gmax - gmin + 1 - a.cap_g);
+  }
+  if (idx < a.n_nodes) {
+    int s;
+    int64_t base = static_cast<int64_t>(a.n_sub) * a.n_targets;
+    if (idx < base) {
+      s = static_cast<int>(idx / a.n_targets);
+    } else {
+      s = 0;
+      for (int h = 0; h < a.n_hops; ++h) {
+        const int64_t blk = static_cast<int64_t>(a.n_sub) * a.cap[h];
+        if (idx < base + blk || h == a.n_hops - 1) { s = static_cast<int>((idx - base) / a.cap[h]); break; }
+        base += blk;
+      }
+    }
+    const int g = a.node_gid[idx];
+    int64_t src = -1, dst = -1;
+    if (g >= 0) {
+      const int w = a.win_start[s];
+      const int gmin = a.group_of[w], gmax = a.group_of[w + a.n_targets - 1];
+      const int gg = a.group_of[g];
+      if (gg >= gmin && gg <= gmax && gg - gmin < a.cap_g) {
+        src = idx;
+        dst = static_cast<int64_t>(s) * a.cap_g + (gg - gmin);
+      }
+    }
+    a.edges[idx] = src;
+    a.edges[a.n_nodes + idx] = dst;
+  }
+}
+
 // out[i, :] = gid[i] >= 0 ? src[gid[i], :] : 0   (float rows, H % 4 == 0; one 16-lane group per row)
 __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ gid,
                                                      int64_t n, int32_t H4, float* __restrict__ out, int64_t ld_out) {
@@ -292,6 +345,28 @@ extern "C" int agnn_sample_hops(const agnn_sampler_t* cfg, agnn_stream_t stream_
   SamplerArgs A{c};
   hipLaunchKernelGGL(k_sample_hops, dim3(static_cast<unsigned>(c.n_sub)), dim3(kThreads), 0, static_cast<hipStream_t>(stream_), A);
   return check_launch("sample_hops");
+}
+
+extern "C" int agnn_sample_members(const int32_t* node_gid, int64_t n_nodes, const int32_t* group_of, const int32_t* win_start,
+                                   int32_t n_sub, int32_t n_targets, int32_t n_hops, const int32_t* cap, int32_t cap_g,
+                                   int32_t* group_gid, int64_t* edges, int32_t* drops, agnn_stream_t stream_) {
+  using namespace agnn;
+  if (n_sub <= 0 || n_targets <= 0 || cap_g <= 0 || n_hops < 0 || n_hops > AGNN_SAMPLER_MAX_HOPS || (n_hops > 0 && !cap))
+    return fail(AGNN_EINVAL, "sample_members: n_sub=%d n_targets=%d n_hops=%d cap_g=%d", n_sub, n_targets, n_hops, cap_g);
+  int64_t expect = static_cast<int64_t>(n_sub) * n_targets;
+  MemberArgs a{};
+  for (int h = 0; h < n_hops; ++h) {
+    if (cap[h] <= 0) return fail(AGNN_EINVAL, "sample_members: cap[%d]=%d", h, cap[h]);
+    a.cap[h] = cap[h];
+    expect += static_cast<int64_t>(n_sub) * cap[h];
+  }
+  if (n_nodes != expect) return fail(AGNN_EINVAL, "sample_members: n_nodes=%lld, the hop layout has %lld slots", (long long)n_nodes, (long long)expect);
+  if (!node_gid || !group_of || !win_start || !group_gid || !edges) return fail(AGNN_EINVAL, "sample_members: null argument");
+  a.node_gid = node_gid; a.group_of = group_of; a.win_start = win_start; a.group_gid = group_gid; a.edges = edges; a.drops = drops;
+  a.n_nodes = n_nodes; a.n_sub = n_sub; a.n_targets = n_targets; a.n_hops = n_hops; a.cap_g = cap_g;
+  const int64_t work = n_nodes > static_cast<int64_t>(n_sub) * cap_g ? n_nodes : static_cast<int64_t>(n_sub) * cap_g;
+  hipLaunchKernelGGL(k_sample_members, dim3(static_cast<unsigned>((work + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), a);
+  return check_launch("sample_members");
 }
 
 extern "C" int agnn_gather_rows_f32(const float* src, int64_t ld_src, const int32_t* gid, int64_t n, int32_t H, float* out, int64_t ld_out,

@@ -721,6 +721,7 @@ def attention_roofline_case(g, I, hid: int, dev, timed, hbm_peak: float, heads: 
     b_alg, e_tot = 0, 0
     for et in ets:
         ei = g.edge_index[et]
+        ei = ei[:, ei[0] >= 0]                                   # (-1, -1): padding slots of a device-sampled batch
         e_tot += int(ei.shape[1])
         b_alg += 4 * (n + 1) + 4 * int(ei.shape[1]) + 2 * 4 * hid * int(np.unique(ei[0]).size)
     b_alg += 2 * 4 * hid * n + 2 * 4 * heads * n

@@ -49,13 +49,17 @@ WORKLOADS = {
     "c2d": "C2 with the batch assembled ON THE DEVICE inside the timed step: 64 scores x 1500 notes resident in HBM, every step "
            "samples 32 fresh windows x (500 target notes + [5,5] hops) into static-shape buffers (agnn_sample_hops), gathers their "
            "features, rebuilds the CSR and trains on them; HybridGNN L=3 H=256 out=128, 21 task heads",
+    "c3d": "C3 with the batch assembled ON THE DEVICE inside the timed step: 64 scores x 1500 notes with their beats and measures "
+           "resident in HBM, every step samples 32 fresh windows x (500 target notes + [5,5] hops), adds each window's beats / measures "
+           "and the notes' membership edges (agnn_sample_hops + agnn_sample_members), gathers features, rebuilds the CSR and trains; "
+           "HGT L=3 H=256 heads=4, 6 relation types, 21 task heads",
     "c3": "C3: HGT L=3 H=256 heads=4, note+beat+measure nodes, 6 relation types, 21 task heads, 32 subgraphs x 500 notes per GPU "
           "(whole graphs)",
     "c5": "C5: MetricalGNN L=4 H=512, heads cadence/localkey/romanNumeral, 32 subgraphs x 500 notes per GPU (whole graphs)",
 }
 METRICS = {"c2s": "subgraph-nodes/sec fwd+bwd, HybridGNN L=3 H=256", "c2": "subgraph-nodes/sec fwd+bwd, HybridGNN L=3 H=256",
            "c2d": "subgraph-nodes/sec fwd+bwd, HybridGNN L=3 H=256",
-           "c3": "subgraph-nodes/sec fwd+bwd, HGT L=3 H=256", "c5": "subgraph-nodes/sec fwd+bwd, MetricalGNN L=4 H=512"}
+           "c3": "subgraph-nodes/sec fwd+bwd, HGT L=3 H=256", "c3d": "subgraph-nodes/sec fwd+bwd, HGT L=3 H=256", "c5": "subgraph-nodes/sec fwd+bwd, MetricalGNN L=4 H=512"}
 
 
 def parse_args(argv=None):
@@ -135,7 +139,7 @@ def build_workload(name: str, rank: int, world: int, n_sub: int = N_SUB):
         return g, "hybridgnn", H, LAYERS, TASK_DICT
     if name == "c2":
         return make_batch(n_sub, N_NOTES, seeds=seeds), "hybridgnn", H, LAYERS, TASK_DICT
-    if name == "c3":
+    if name in ("c3", "c3d"):                      # c3d's shapes for the host-side helpers: the same kind of graphs
         g = make_batch(n_sub, N_NOTES, seeds=seeds, add_beats=True, add_measures=True)
         keep = [et for et in g.edge_types if et[0] == "note"]       # 4 note-note + note->beat + note->measure
         g.edge_index = {et: g.edge_index[et] for et in keep}
@@ -288,14 +292,19 @@ def main():
 
     g, enc, hid, layers, tasks = build_workload(args.workload, rank, world)
     sampler = None
-    if args.workload == "c2d":
+    if args.workload in ("c2d", "c3d"):
         import numpy as np
         from analysisgnn_amd.batching import DeviceSampler, ScoreStore
         from analysisgnn_amd.synth import make_score_graph
         # the corpus (replicated on every rank, as a dataset would be): 64 synthetic scores of 1500 notes; ranks draw
         # different windows (their own host generator), i.e. disjoint subgraphs of the global batch
-        store = ScoreStore([make_score_graph(seed=1000 + i, n_notes=1500) for i in range(64)], IN_CH, dev, tasks=tasks, seed=0)
+        hetero = args.workload == "c3d"
+        scores = [make_score_graph(seed=1000 + i, n_notes=1500, add_beats=hetero, add_measures=hetero) for i in range(64)]
+        for sg in scores:                                           # C3's relation set: the types whose source is a note
+            sg.edge_index = {et: e for et, e in sg.edge_index.items() if et[0] == "note"}
+        store = ScoreStore(scores, IN_CH, dev, tasks=tasks, seed=0)
         sampler = DeviceSampler(store, N_SUB, N_NOTES, (5,) * (layers - 1), (32,) * (layers - 1), seed=1 + rank)
+        g_meta = sampler.metadata()
         win_rng = np.random.default_rng(100 + rank)
         sampler.set_windows(store.random_windows(N_SUB, N_NOTES, win_rng))
         I = sampler.sample()
@@ -304,8 +313,8 @@ def main():
         I = torch_inputs(g, IN_CH, dev, seed=rank)
         labels = make_labels(I["batch_size"], dev, 100 + rank, tasks)
     torch.manual_seed(0)                                            # identical replicas
-    model = TorchAnalysisGNN(g.metadata(), IN_CH, hid, OUT, tasks, layers, dropout=0.3, use_jk=False, logit_fusion=False,
-                             encoder_type=enc).to(dev).train()
+    model = TorchAnalysisGNN(g_meta if sampler is not None else g.metadata(), IN_CH, hid, OUT, tasks, layers, dropout=0.3, use_jk=False,
+                             logit_fusion=False, encoder_type=enc).to(dev).train()
     clf_loss = MultiTaskLoss(list(tasks), requires_grad=(args.mt_strategy == "wloss")).to(dev)     # analysis.py:899-908
     trainable = torch.nn.ModuleDict({"model": model, "clf_loss": clf_loss})
     # parameters consumed concatenated (task-head layers, GRU direction pairs) sit back to back: their cats are views
@@ -458,7 +467,7 @@ def main():
 
     if sampler is not None:                                         # the roofline launch runs on the LAST sampled batch
         g.edge_index = {et: e.cpu().numpy() for et, e in I["edge_index_dict"].items()}
-        g.num_nodes = {"note": sampler.num_nodes}
+        g.num_nodes = {t: int(v.shape[0]) for t, v in I["x_dict"].items()}
     roof = roofline(args.workload, g, I, hid, layers, dev) if rank == 0 else None
     if rank == 0:
         nodes = I["batch_size"] * world * args.steps
@@ -475,7 +484,7 @@ def main():
                                    + ("hipGraph replay" if graphs is not None else "EAGER launches (see \"graph\")"),
                        "workload_id": args.workload, "per_gpu_subgraphs": N_SUB, "target_notes_per_subgraph": N_NOTES,
                        "objective": args.mt_strategy,
-                       "sharding": ("every rank draws its own windows from the replicated corpus" if args.workload == "c2d"
+                       "sharding": ("every rank draws its own windows from the replicated corpus" if sampler is not None
                                     else "rank r takes subgraphs {i : i mod G = r}"),
                        "parallelism": f"dp{world}"},
             "roofline": roof,
@@ -489,7 +498,7 @@ def main():
             # secondary figures, each a child process with the same steps: "c2" = continuity with round 1's line (whole graphs,
             # nothing trimmed); "c2d" = the same training step with the batch sampled and gathered ON THE DEVICE inside it
             out["other_workloads"] = {}
-            for wl in ("c2", "c2d", "c3", "c5"):
+            for wl in ("c2", "c2d", "c3", "c3d", "c5"):
                 try:
                     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", wl, "--no-cpu-baseline", "--steps",
                                         str(args.steps), "--warmup", str(args.warmup), "--mt-strategy", args.mt_strategy],
@@ -540,7 +549,7 @@ def roofline(workload, g, I, hid, layers, dev):
         ts = ts[2:]
         return sum(ts) / len(ts), len(ts) * per
 
-    if workload == "c3":
+    if workload in ("c3", "c3d"):
         from analysisgnn_amd.hgt import attention_roofline_case
         return attention_roofline_case(g, I, hid, dev, timed, HBM_PEAK)
 

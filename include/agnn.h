@@ -491,6 +491,20 @@ typedef struct {
 int64_t agnn_sampler_num_nodes(const agnn_sampler_t* cfg /* (host) */);
 int64_t agnn_sampler_edge_capacity(const agnn_sampler_t* cfg /* (host) */);
 int agnn_sample_hops(const agnn_sampler_t* cfg /* (host) */, agnn_stream_t stream);
+/* Metrical nodes of a sampled batch (the reference's graphs carry beat and measure nodes unless `remove_beats/measures` is set,
+ * ref data/datamodules/analysis.py:213-225; every note belongs to one beat and one measure, hgraph edge type
+ * (note, connects, beat|measure)).  `group_of` (device int32 [n_notes_total]): the global id of the note's group, non-decreasing
+ * inside a score (notes are sorted by onset), so the groups of a window's target notes are ONE contiguous range
+ * [group_of[w], group_of[w + n_targets - 1]] — no set, no sort.  After agnn_sample_hops (same layout arguments):
+ *   group_gid [n_sub * cap_g]   subgraph s owns slots [s*cap_g, (s+1)*cap_g): its range in ascending id, -1 in unused slots
+ *                               (`drops`, optional, counts groups beyond the capacity);
+ *   edges int64 [2, n_nodes]    slot i = batch note i: (i, batch-local group slot) when the note's group lies in its subgraph's
+ *                               range, else (-1, -1).  Slot order = node order, so the per-hop edge counts that drive
+ *                               trim_to_layer are [n_sub*(n_targets + cap[0]), n_sub*cap[1], ...]: an edge is trimmed with
+ *                               its source note's hop block; the group nodes themselves are all hop-0 (never trimmed). */
+int agnn_sample_members(const int32_t* node_gid, int64_t n_nodes, const int32_t* group_of, const int32_t* win_start,
+                        int32_t n_sub, int32_t n_targets, int32_t n_hops, const int32_t* cap /* (host) [n_hops] */,
+                        int32_t cap_g, int32_t* group_gid, int64_t* edges, int32_t* drops, agnn_stream_t stream);
 int agnn_gather_rows_f32(const float* src, int64_t ld_src, const int32_t* gid, int64_t n, int32_t H, float* out,
                          int64_t ld_out, agnn_stream_t stream);
 int agnn_gather_i64(const int64_t* src, int64_t ld_src, const int32_t* gid, int64_t n, int32_t n_vec, int64_t fill,

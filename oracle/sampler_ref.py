@@ -103,3 +103,43 @@ def sample_hops(rowptr: Sequence[np.ndarray], col: Sequence[np.ndarray], win_sta
             nbase += B * cap[h]
             frontier, Fcap = kept, cap[h]
     return node_gid, edges, dropped
+
+
+def sample_members(node_gid: np.ndarray, group_of: np.ndarray, win_start: Sequence[int], n_targets: int, cap: Sequence[int], cap_g: int):
+    """CPU restatement of `agnn_sample_members` (include/agnn.h): the metrical nodes (beats / measures) of a sampled batch and
+    the (note, connects, group) membership edges of its notes.  -> (group_gid int32 [B * cap_g], edges int64 [2, n_nodes], dropped).
+    The build's own contract (graphmuse's loader is absent: the CHOICE of nodes is parity unpinned, the layout invariants —
+    contiguous ranges, an edge only between a note and a group of its own subgraph, edge slot = note slot — are properties)."""
+    B, T = len(win_start), int(n_targets)
+    n_nodes = int(node_gid.shape[0])
+    assert n_nodes == B * T + sum(B * c for c in cap)
+    group_gid = np.full(B * cap_g, -1, dtype=np.int32)
+    edges = np.full((2, n_nodes), -1, dtype=np.int64)
+    dropped = 0
+    rng = []
+    for s in range(B):
+        w = int(win_start[s])
+        gmin, gmax = int(group_of[w]), int(group_of[w + T - 1])
+        rng.append((gmin, gmax))
+        for j in range(cap_g):
+            if gmin + j <= gmax:
+                group_gid[s * cap_g + j] = gmin + j
+        dropped += max(0, gmax - gmin + 1 - cap_g)
+    blocks = [(0, T)]
+    base = B * T
+    for c in cap:
+        blocks.append((base, c))
+        base += B * c
+    for base, width in blocks:
+        for s in range(B):
+            gmin, gmax = rng[s]
+            for i in range(width):
+                slot = base + s * width + i
+                g = int(node_gid[slot])
+                if g < 0:
+                    continue
+                gg = int(group_of[g])
+                if gmin <= gg <= gmax and gg - gmin < cap_g:
+                    edges[0, slot] = slot
+                    edges[1, slot] = s * cap_g + (gg - gmin)
+    return group_gid, edges, dropped

@@ -240,3 +240,109 @@ def test_sampled_step_replays_from_one_graph_with_a_fresh_batch_each_time():
         assert len(set(losses)) == 3                                # three different batches
     finally:
         graph.index_cache_enabled = was
+
+
+def _hetero_store(n_scores=4, n_notes=800, tasks=None):
+    from analysisgnn_amd.batching import ScoreStore
+    from analysisgnn_amd.synth import make_score_graph
+    graphs = [make_score_graph(seed=80 + i, n_notes=n_notes, add_beats=True, add_measures=True) for i in range(n_scores)]
+    for g in graphs:                                   # the C3 relation set: four note-note types + note->beat + note->measure
+        g.edge_index = {et: e for et, e in g.edge_index.items() if et[0] == "note"}
+    return ScoreStore(graphs, 25, DEV, tasks=tasks or {"cadence": 4, "localkey": 50}, seed=3), graphs
+
+
+@pytest.mark.parametrize("fan,cap,T,gcap", [((5, 5), (64, 64), 500, {"beat": 160, "measure": 48}), ((3,), (32,), 64, {"beat": 24, "measure": 4})])
+def test_metrical_members_match_oracle_bit_for_bit(fan, cap, T, gcap):
+    """Beats / measures of a sampled batch (agnn_sample_members) against oracle/sampler_ref.sample_members: group slots, membership
+    edge slots, gathered features — integers compared exactly; the second case is tight enough to cut groups (counted in
+    `drops`, not an error)."""
+    from analysisgnn_amd import _lib
+    from analysisgnn_amd.batching import DeviceSampler
+    from oracle import sampler_ref as S
+    store, graphs = _hetero_store()
+    assert store.group_types == ["beat", "measure"]
+    B = 5
+    smp = DeviceSampler(store, B, T, fan, cap, seed=11, group_capacity=gcap)
+    assert smp.metadata()[1][-2:] == [("note", "connects", "beat"), ("note", "connects", "measure")]
+    rng = np.random.default_rng(2)
+    wins = store.random_windows(B, T, rng)
+    smp.set_windows(wins)
+    batch = smp.sample()
+    torch.cuda.synchronize()
+    gid = smp.node_gid.cpu().numpy()
+    dropped = 0
+    for t in store.group_types:
+        gof = store.group_of[t].cpu().numpy()
+        ggid, edges, dr = S.sample_members(gid, gof, wins, T, cap, gcap[t])
+        dropped += dr
+        assert np.array_equal(smp.group_gid[t].cpu().numpy(), ggid), t
+        e = batch["edge_index_dict"][("note", "connects", t)].cpu().numpy()
+        assert np.array_equal(e, edges), t
+        live = e[0] >= 0
+        assert live.sum() >= B * T * 0.9 if not dr else live.sum() > 0          # (nearly) every target note has its beat / measure
+        # an edge joins a note and a group of the SAME subgraph, and the group is the note's own
+        sub_note = batch["batch_dict"]["note"].cpu().numpy()[e[0][live]]
+        sub_grp = batch["batch_dict"][t].cpu().numpy()[e[1][live]]
+        assert np.array_equal(sub_note, sub_grp)
+        assert np.array_equal(gof[gid[e[0][live]]], ggid[e[1][live]])
+        gg = torch.from_numpy(ggid.astype(np.int64)).to(DEV)
+        real = gg >= 0
+        assert torch.equal(smp.group_x[t][real], store.group_x[t][gg[real]]) and float(smp.group_x[t][~real].abs().sum()) == 0.0
+        assert batch["neighbor_mask_node"][t] == [B * gcap[t]] + [0] * len(cap)
+        assert sum(batch["neighbor_mask_edge"][("note", "connects", t)]) == smp.num_nodes
+    assert (dropped > 0) == (T == 64)
+    assert smp.dropped() >= dropped
+    _lib.check_device_status(DEV)
+
+
+def test_hgt_on_the_padded_hetero_batch_equals_the_compact_batch():
+    """C3's encoder (HybridHGT, note + beat + measure, six relation types) on the static-shape batch the device sampler writes
+    (padding notes / groups / (-1, -1) edge slots, per-hop CAPACITIES as trim counts) against the CPU restatement on the same
+    subgraphs compacted the way a loader would hand them over (real per-hop counts): target rows agree to 1e-4."""
+    from analysisgnn_amd.batching import DeviceSampler
+    from analysisgnn_amd.hgt import HybridHGT
+    from oracle import encoders_ref as E
+    store, _ = _hetero_store(tasks={"a": 3})
+    B, T, H = 3, 200, 32
+    smp = DeviceSampler(store, B, T, (5, 5), (48, 48), seed=2, group_capacity={"beat": 72, "measure": 24})
+    smp.set_windows(store.random_windows(B, T, np.random.default_rng(4)))
+    batch = smp.sample()
+    torch.cuda.synchronize()
+    assert smp.dropped() == 0
+    md = smp.metadata()
+    torch.manual_seed(1)
+    m = HybridHGT(metadata=md, input_channels=H, hidden_channels=H, num_layers=3, heads=4, dropout=0.0).eval()
+    P = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV)
+    gen = torch.Generator().manual_seed(5)
+    ids = {"note": smp.node_gid.cpu().long(), **{t: smp.group_gid[t].cpu().long() for t in store.group_types}}
+    total = {"note": store.num_notes, **{t: int(store.group_x[t].shape[0]) for t in store.group_types}}
+    x = {}
+    for t in md[0]:
+        feat = torch.randn(total[t], H, generator=gen)
+        x[t] = torch.where((ids[t] >= 0).unsqueeze(1), feat[ids[t].clamp(min=0)], torch.zeros(1, H))
+    with torch.no_grad():
+        out = m(x_dict={t: v.to(DEV) for t, v in x.items()}, edge_index_dict=batch["edge_index_dict"], batch_dict=batch["batch_dict"],
+                batch_size=smp.batch_size, neighbor_mask_node=batch["neighbor_mask_node"], neighbor_mask_edge=batch["neighbor_mask_edge"])
+    keep = {t: ids[t] >= 0 for t in md[0]}
+    new_id = {t: torch.cumsum(keep[t].long(), 0) - 1 for t in md[0]}
+    nodes_per_hop = {}
+    for t in md[0]:
+        nb = np.concatenate([[0], np.cumsum(smp.num_sampled_nodes[t])])
+        nodes_per_hop[t] = [int(keep[t][nb[h]:nb[h + 1]].sum()) for h in range(len(nb) - 1)]
+    ei_c, edges_per_hop = {}, {}
+    for et, e in batch["edge_index_dict"].items():
+        e = e.cpu()
+        counts, parts, lo = [], [], 0
+        for eh in smp.num_sampled_edges[et]:
+            seg = e[:, lo:lo + eh]
+            seg = seg[:, seg[0] >= 0]
+            parts.append(torch.stack([new_id[et[0]][seg[0]], new_id[et[2]][seg[1]]]))
+            counts.append(int(seg.shape[1]))
+            lo += eh
+        ei_c[et], edges_per_hop[et] = torch.cat(parts, dim=1), counts
+    xc = {t: x[t][keep[t]] for t in md[0]}
+    bc = {t: batch["batch_dict"][t].cpu()[keep[t]] for t in md[0]}
+    with torch.no_grad():
+        ref = E.hybrid_hgt(P, "", md, 3, 4, xc, ei_c, bc, smp.batch_size, nodes_per_hop, edges_per_hop)
+    assert_close(out, ref, 1e-4, "padded hetero batch vs compact batch")

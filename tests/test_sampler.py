@@ -94,3 +94,32 @@ def test_capacity_overflow_is_counted_not_silent():
     for e in edges:                                     # edges to dropped nodes are not emitted
         live = e[0] >= 0
         assert (gid[e[0][live]] >= 0).all()
+
+
+def test_members_oracle_invariants():
+    """sample_members: a subgraph's groups are the contiguous range of its target window; every live edge slot i is (i, the slot
+    of note i's own group inside ITS subgraph's block); groups beyond the capacity are counted."""
+    from analysisgnn_amd.synth import make_score_graph
+    graphs = [make_score_graph(seed=20 + i, n_notes=600, add_beats=True) for i in range(3)]
+    start = np.concatenate([[0], np.cumsum([g.num_nodes["note"] for g in graphs])])
+    goff = np.concatenate([[0], np.cumsum([g.num_nodes["beat"] for g in graphs])])
+    group_of = np.concatenate([g.edge_index[("note", "connects", "beat")][1] + o for g, o in zip(graphs, goff[:-1])]).astype(np.int32)
+    wins = [int(start[0]) + 50, int(start[2]) + 100]
+    T, cap = 120, (16,)
+    rng = np.random.default_rng(0)
+    node_gid = np.full(2 * T + 2 * 16, -1, dtype=np.int32)
+    for s, w in enumerate(wins):
+        node_gid[s * T:(s + 1) * T] = np.arange(w, w + T)
+        node_gid[2 * T + s * 16:2 * T + s * 16 + 9] = rng.integers(start[[0, 2][s]], start[[0, 2][s] + 1], 9)      # hop nodes of the same score
+    for cap_g in (64, 10):
+        ggid, edges, dropped = S.sample_members(node_gid, group_of, wins, T, cap, cap_g)
+        for s, w in enumerate(wins):
+            lo, hi = int(group_of[w]), int(group_of[w + T - 1])
+            blk = ggid[s * cap_g:(s + 1) * cap_g]
+            n = min(hi - lo + 1, cap_g)
+            assert np.array_equal(blk[:n], np.arange(lo, lo + n)) and (blk[n:] == -1).all()
+        live = edges[0] >= 0
+        assert np.array_equal(edges[0][live], np.nonzero(live)[0])
+        assert np.array_equal(ggid[edges[1][live]], group_of[node_gid[edges[0][live]]])
+        assert (edges[1][~live] == -1).all() and (node_gid[~live & (np.arange(node_gid.size) < 2 * T)] >= 0).sum() == (0 if cap_g == 64 else (~live[:2 * T]).sum())
+        assert (dropped > 0) == (cap_g == 10)
