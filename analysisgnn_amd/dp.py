@@ -54,9 +54,11 @@ def _aligned_offsets(sizes: Sequence[int], align: int = 4, tight: Optional[Seque
     return offs
 
 
-def plan_parameters(model: torch.nn.Module):
+def plan_parameters(model: torch.nn.Module, late: Iterable[torch.nn.Parameter] = ()):
     """(params, tight): the trainable parameters in the order the flat buffers should hold them, and the ids of those that
-    must sit right behind their predecessor.  Modules may expose `adjacent_parameter_groups()` -> lists of parameters
+    must sit right behind their predecessor.  `late`: parameters whose gradients the backward pass produces LAST (the input
+    layers) — placed at the END of the buffer so that everything before them is one contiguous message that can be all-reduced
+    while they are still being computed (FlatGradBuffer(late=...), all_reduce_early_async).  Modules may expose `adjacent_parameter_groups()` -> lists of parameters
     that the hot path consumes concatenated (task-head layers, GRU direction pairs): laid out back to back, the cat /
     stack is a view of the flat parameter buffer instead of a launch per step (params.cat_rows / stack_rows).  All other
     parameters follow in `model.parameters()` order."""
@@ -65,18 +67,22 @@ def plan_parameters(model: torch.nn.Module):
         fn = getattr(m, "adjacent_parameter_groups", None)
         if fn is not None:
             groups.extend([[p for p in g] for g in fn()])
+    late_ids = {id(p) for p in late}
     seen, params, tight = set(), [], set()
     for g in groups:
+        if any(id(p) in late_ids for p in g):
+            raise ValueError("plan_parameters: an adjacency group cannot hold late parameters")
         g = [p for p in g if p.requires_grad and id(p) not in seen]
         for i, p in enumerate(g):
             seen.add(id(p))
             params.append(p)
             if i > 0:
                 tight.add(id(p))
-    for p in model.parameters():
-        if p.requires_grad and id(p) not in seen:
-            seen.add(id(p))
-            params.append(p)
+    for want_late in (False, True):
+        for p in model.parameters():
+            if p.requires_grad and id(p) not in seen and (id(p) in late_ids) == want_late:
+                seen.add(id(p))
+                params.append(p)
     return params, tight
 
 
@@ -91,7 +97,11 @@ class FlatGradBuffer:
         `.grad` then become views of the buffer so the optimizer sees the reduced / clipped values.
     """
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], views: bool = True, tight: Optional[set] = None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], views: bool = True, tight: Optional[set] = None,
+                 late: Iterable[torch.nn.Parameter] = ()):
+        """`late`: the parameters of the second bucket (must be the LAST ones of `params`, dp.plan_parameters(model, late=...)
+        puts them there): `pack("early")` / `pack("late")` gather the two buckets separately, `all_reduce_early_async` ships
+        the first while the backward pass still works on the second."""
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -109,6 +119,14 @@ class FlatGradBuffer:
         self._pad = torch.zeros(4, dtype=torch.float32, device=dev)
         # a parameter that took no gradient this step (a layer that keeps no edge: encoders.HeteroConv) packs from here
         self._none = torch.zeros(max(self.sizes) if self.sizes else 1, dtype=torch.float32, device=dev)
+        late_ids = {id(p) for p in late}
+        self.n_early = len(self.params)
+        if late_ids:
+            flags = [id(p) in late_ids for p in self.params]
+            self.n_early = flags.index(True) if True in flags else len(flags)
+            if not all(flags[self.n_early:]) or sum(flags) != len(late_ids):
+                raise ValueError("FlatGradBuffer: the late parameters must be the last ones of the buffer (dp.plan_parameters(model, late=...))")
+        self.cut = self.offsets[self.n_early]                # flat[:cut] = early bucket, flat[cut:] = late bucket
         if views:
             self._assign_views()
 
@@ -122,29 +140,60 @@ class FlatGradBuffer:
         else:
             for p in self.params:
                 p.grad = None
-            self._packed = False
+            self._packed = set()
 
-    def pack(self) -> None:
-        """views=False: gather the fresh gradients into the flat buffer (one launch).  Also the join point of the
-        weight-gradient stream (linear.enable_wgrad_overlap)."""
+    def pack(self, part: Optional[str] = None) -> None:
+        """views=False: gather the fresh gradients into the flat buffer (one launch; `part` = "early" / "late": one bucket, one
+        launch each).  Also the join point of the weight-gradient stream (linear.enable_wgrad_overlap)."""
         from .linear import join_wgrad
         join_wgrad()
-        if self.views or getattr(self, "_packed", False):
+        if self.views:
             return
-        self._packed = True
-        parts = []
-        for p, k, o, o_next in zip(self.params, self.sizes, self.offsets, self.offsets[1:]):
-            parts.append(p.grad.reshape(-1) if p.grad is not None else self._none[:k])
-            if o_next - o > k:
-                parts.append(self._pad[: o_next - o - k])
-        torch.cat(parts, out=self.flat)
-        self._assign_views()
+        done = getattr(self, "_packed", set())
+        if not isinstance(done, set):
+            done = {"early", "late"} if done else set()
+        for name, lo, hi in (("early", 0, self.n_early), ("late", self.n_early, len(self.params))):
+            if (part is not None and part != name) or name in done or lo == hi:
+                done.add(name) if lo == hi else None
+                continue
+            parts = []
+            for i in range(lo, hi):
+                p, k, o, o_next = self.params[i], self.sizes[i], self.offsets[i], self.offsets[i + 1]
+                parts.append(p.grad.reshape(-1) if p.grad is not None else self._none[:k])
+                if o_next - o > k:
+                    parts.append(self._pad[: o_next - o - k])
+            torch.cat(parts, out=self.flat[self.offsets[lo]:self.offsets[hi]])
+            for i in range(lo, hi):
+                p, k, o = self.params[i], self.sizes[i], self.offsets[i]
+                p.grad = self.flat[o:o + k].view_as(p)
+            done.add(name)
+        self._packed = done
 
     def all_reduce_mean(self, world: Optional[int] = None) -> None:
         """SUM over ranks then divide: the same mean DDP applies."""
         self.pack()
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(dist.get_world_size())
+
+    def all_reduce_early_async(self):
+        """Bucket 1 of 2 (what Lightning DDP's reverse-order buckets do, train/train_analysisgnn.py:246-255): gather and ship
+        everything but the late parameters NOW — the collective runs on the communicator's stream beside whatever the caller
+        queues next (the input layers' backward).  Returns the work handle for `all_reduce_late_and_finish` (None: one rank)."""
+        self.pack("early")
+        if dist.is_initialized() and dist.get_world_size() > 1 and self.cut > 0:
+            return dist.all_reduce(self.flat[:self.cut], op=dist.ReduceOp.SUM, async_op=True)
+        return None
+
+    def all_reduce_late_and_finish(self, work) -> None:
+        """Bucket 2 of 2 (small: the input layers), then wait for bucket 1 and divide: the buffer holds the mean, bit-identical
+        to `all_reduce_mean` (SUM over ranks is element-wise: where a message is cut does not change a sum)."""
+        self.pack("late")
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            if self.cut < self.flat.numel():
+                dist.all_reduce(self.flat[self.cut:], op=dist.ReduceOp.SUM)
+            if work is not None:
+                work.wait()
             self.flat.div_(dist.get_world_size())
 
     def clip_norm_(self, max_norm: float) -> torch.Tensor:

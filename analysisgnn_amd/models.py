@@ -106,6 +106,23 @@ class TorchAnalysisGNN(nn.Module):
     # kernels behind ctypes calls inside autograd.Functions — nothing for a tracing compiler to fuse, and nothing it can trace
     # through.  The three entry points are excluded from tracing as a whole, so a compiled wrapper runs this code unchanged
     # (one clean graph break at the boundary instead of one per kernel call).
+    # Data-parallel steps (dp.FlatGradBuffer(late=model.late_parameters())): with `split_backward = True` the autograd graph is
+    # cut behind the input layers, `loss.backward()` ends there — every gradient but theirs exists and can be all-reduced —
+    # and `finish_backward()` runs the input layers' backward beside the collective.  Same kernels, same order: the
+    # gradients are bit-identical to the unsplit step.
+    split_backward = False
+
+    def late_parameters(self):
+        """The parameters whose gradients the backward pass produces last: the input MLPs and the two embedding tables."""
+        return [*self.project_dict.parameters(), *self.pitch_embedding.parameters(), *self.key_embedding.parameters()]
+
+    def finish_backward(self) -> None:
+        cut, self._cut = getattr(self, "_cut", None), None
+        if cut:
+            live = [(h, leaf.grad) for h, leaf in cut if leaf.grad is not None]
+            if live:
+                torch.autograd.backward([h for h, _ in live], [g for _, g in live])
+
     @torch._dynamo.disable
     def encode(self, pitch_spelling, key_signature, x_dict, edge_index_dict, batch_dict, batch_size,
                neighbor_mask_node, neighbor_mask_edge):
@@ -116,6 +133,14 @@ class TorchAnalysisGNN(nn.Module):
         z_dict["note"] = embed_cat(z_dict["note"], [pitch_spelling, key_signature],
                                    [self.pitch_embedding.weight, self.key_embedding.weight])
         h_dict = {k: self.project_dict[k](z_dict[k]) for k in self.project_dict.keys()}
+        self._cut = None
+        if self.split_backward and torch.is_grad_enabled():
+            self._cut = []
+            for k, hk in list(h_dict.items()):
+                if hk.requires_grad:
+                    leaf = hk.detach().requires_grad_(True)
+                    self._cut.append((hk, leaf))
+                    h_dict[k] = leaf
         x = self.encoder(x_dict=h_dict, edge_index_dict=edge_index_dict, batch_dict=batch_dict,
                          batch_size=batch_size, neighbor_mask_node=neighbor_mask_node,
                          neighbor_mask_edge=neighbor_mask_edge, return_edge_index=False, edge_attr_dict=None)

@@ -82,6 +82,8 @@ def parse_args(argv=None):
     ap.add_argument("--blas", default=None, choices=[None, "hipblaslt", "rocblas"], help="A/B only: torch's preferred BLAS library")
     ap.add_argument("--graph-dot", default=None, help="debugging: write the captured step's dependency graph as DOT to this path")
     ap.add_argument("--host-times", action="store_true", help="debugging: report the host time inside the replay calls")
+    ap.add_argument("--one-bucket", action="store_true", help="N > 1, A/B only: one gradient message between the two graph replays "
+                    "instead of two buckets with the first all-reduce beside the input layers' backward")
     ap.add_argument("--no-other", action="store_true", help="skip the secondary (whole-graph C2) measurement of the default run")
     return ap.parse_args(argv)
 
@@ -318,8 +320,13 @@ def main():
     clf_loss = MultiTaskLoss(list(tasks), requires_grad=(args.mt_strategy == "wloss")).to(dev)     # analysis.py:899-908
     trainable = torch.nn.ModuleDict({"model": model, "clf_loss": clf_loss})
     # parameters consumed concatenated (task-head layers, GRU direction pairs) sit back to back: their cats are views
-    params, tight = dp.plan_parameters(trainable)
-    flat = dp.FlatGradBuffer(params, views=False, tight=tight)
+    # N > 1: the input layers' parameters (their gradients come last) form a second, small bucket at the end of the flat buffer;
+    # the first bucket (everything else, ~98 % of the message) is all-reduced while their backward still runs
+    buckets = world > 1 and not args.one_bucket
+    late = model.late_parameters() if buckets else []
+    model.split_backward = buckets
+    params, tight = dp.plan_parameters(trainable, late=late)
+    flat = dp.FlatGradBuffer(params, views=False, tight=tight, late=late)
     # the GRU layers' weight-gradient work on its own stream, joined in flat.pack() — only where the sequence branch is
     # the longer one (C2; with HGT / MetricalGNN the graph branch is, and the extra stream only adds contention)
     dp.enable_wgrad_overlap(not args.no_wgrad_overlap and args.workload in ("c2", "c2s"), "sequence")
@@ -348,9 +355,23 @@ def main():
         loss, _ = training_loss(logits, offs, label_mat, x, 0.1, 0.1, -1, task_params=clf_loss.weights())   # analysis.py:1034-1036, :1072
         _lib_stamp("forward + objective issued (main)")
         loss.backward(gradient=one)                                # a resident 1.0: no fill launch for the root gradient
-        flat.pack()
+        flat.pack("early" if buckets else None)                    # two buckets: backward stopped behind the input layers
         _lib_stamp("step end (gradients gathered)")
         return loss
+
+    def bwd_tail():                                                 # two buckets only: the input layers' backward + their bucket's gather
+        model.finish_backward()
+        flat.pack("late")
+
+    def reduce_between(run_tail):
+        """What sits between the step's launches and the optimizer's: the gradient exchange.  Two buckets: ship the first,
+        run the input layers' backward beside it, ship theirs, wait, divide."""
+        if not buckets:
+            flat.all_reduce_mean()
+            return
+        work = flat.all_reduce_early_async()
+        run_tail()
+        flat.all_reduce_late_and_finish(work)
 
     def update():
         opt.step(max_norm=1.0)                                      # clip + AdamW: agnn_adamw_f32 (two launches)
@@ -372,7 +393,7 @@ def main():
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 for _ in range(3):
-                    fwd_bwd(); flat.all_reduce_mean(); update()
+                    fwd_bwd(); reduce_between(bwd_tail); update()
             torch.cuda.current_stream(dev).wait_stream(side)
             dp.barrier_and_sync()                               # no collective in flight on any rank while capturing
             g2 = torch.cuda.CUDAGraph()
@@ -391,6 +412,11 @@ def main():
                     loss_v = fwd_bwd()
                     if dot:
                         _dump_capture_dot(dot, dev)
+                gt = None
+                if buckets:                                      # the tail belongs to THIS capture's autograd graph (model._cut)
+                    gt = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gt, capture_error_mode=cap_mode):
+                        bwd_tail()
                 t_v = 0.0
                 if len(variants) > 1:
                     g1.replay()
@@ -401,15 +427,15 @@ def main():
                     dp.barrier_and_sync()
                     t_v = dp.max_over_ranks(time.perf_counter() - t0)
                 if best is None or t_v < best[0]:
-                    best = (t_v, g1, loss_v, late)
-            _, g1, loss_ref[0], schedule_late = best
+                    best = (t_v, g1, loss_v, late, gt)
+            _, g1, loss_ref[0], schedule_late, g_tail = best
             _enc.LATE_SEQUENCE_BACKWARD = schedule_late
             if rank == 0 and len(variants) > 1:
                 print(f"[bench] backward schedule: sequence branch {'behind a late node' if schedule_late else 'in autograd order'}",
                       file=sys.stderr)
             with torch.cuda.graph(g2, capture_error_mode=cap_mode):
                 update()
-            graphs = (g1, g2)
+            graphs = (g1, g2, g_tail)
             graph_mode = f"hipGraph replay (capture_error_mode={cap_mode})"
         except Exception as e:                                  # capture refused: run eagerly — a HOST-BOUND number, flagged at top level
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
@@ -425,16 +451,16 @@ def main():
                 h0 = time.perf_counter()
                 graphs[0].replay()
                 h1 = time.perf_counter()
-                flat.all_reduce_mean()
+                reduce_between(graphs[2].replay if buckets else None)
                 graphs[1].replay()
                 HOST_T.append((h1 - h0, time.perf_counter() - h1))
                 return loss_ref[0]
             graphs[0].replay()
-            flat.all_reduce_mean()
+            reduce_between(graphs[2].replay if buckets else None)
             graphs[1].replay()
             return loss_ref[0]
         loss = fwd_bwd()
-        flat.all_reduce_mean()
+        reduce_between(bwd_tail)
         update()
         return loss
 
@@ -486,7 +512,10 @@ def main():
                        "objective": args.mt_strategy,
                        "sharding": ("every rank draws its own windows from the replicated corpus" if sampler is not None
                                     else "rank r takes subgraphs {i : i mod G = r}"),
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}",
+                       "allreduce": ("none (one rank)" if world == 1 else
+                                     f"2 buckets: {flat.cut} floats shipped asynchronously beside the input layers' backward, then "
+                                     f"{flat.flat.numel() - flat.cut}; SUM / world" if buckets else "one message between the two graph replays")},
             "roofline": roof,
         }
         # whole-step efficiency as a reported number: algorithmic matrix FLOPs of the step / step time / fp32-MFMA peak

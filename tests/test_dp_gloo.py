@@ -59,9 +59,27 @@ def _worker(rank, world, port, ret):
         out = model(I)
         (out.pow(2).sum() / 48).backward()                      # sum over this rank's 48 target notes / per-rank count
         flat.all_reduce_mean()
+    # the same step with the gradient message cut in two buckets (dp.plan_parameters(late=...): the late parameters at the end of
+    # the buffer, the early bucket shipped asynchronously while "the rest of backward" — here: nothing — runs): bit-identical
+    plist = list(model.parameters())
+    late = plist[:2]                                            # any subset: plan_parameters moves it to the end
+    params, tight = dp.plan_parameters(model, late=late)
+    assert [id(p) for p in params[-2:]] == [id(p) for p in late]
+    fb = dp.FlatGradBuffer(params, views=False, tight=tight, late=late)
+    fb.zero()
+    (model(I).pow(2).sum() / 48).backward()
+    work = fb.all_reduce_early_async()
+    assert work is not None and 0 < fb.cut < fb.flat.numel()
+    fb.all_reduce_late_and_finish(work)
+    by_param = {id(p): p.grad.clone() for p in params}
+    fu = dp.FlatGradBuffer(params, views=False, tight=tight)
+    fu.zero()
+    (model(I).pow(2).sum() / 48).backward()
+    fu.all_reduce_mean()
+    same = all(torch.equal(by_param[id(p)], p.grad) for p in params)
     dp.barrier_and_sync()
     t = dp.max_over_ranks(float(rank + 1))
-    ret[rank] = (units, flat.flat.clone(), t)
+    ret[rank] = (units, flat.flat.clone(), t, same)
     dist.destroy_process_group()
 
 
@@ -71,7 +89,8 @@ def test_two_rank_gradient_mean_matches_single_process():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
-    (u0, g0, t0), (u1, g1, t1) = ret[0], ret[1]
+    (u0, g0, t0, same0), (u1, g1, t1, same1) = ret[0], ret[1]
+    assert same0 and same1                                       # two-bucket all-reduce == one-message all-reduce, bit for bit
     assert sorted(u0 + u1) == [0, 1, 2, 3] and not set(u0) & set(u1)
     assert torch.equal(g0, g1)                                   # replicas hold identical averaged gradients
     assert t0 == t1 == 2.0                                       # MAX over ranks

@@ -326,3 +326,61 @@ def test_nested_wgrad_stream_inside_a_capture():
             assert torch.equal(out, x * 2.0 + 1.0)
     finally:
         dp.enable_wgrad_overlap(False)
+
+
+def test_split_backward_two_buckets_equal_the_unsplit_step():
+    """N > 1 schedule of bench.py on one rank: the autograd graph cut behind the input layers (models.split_backward), the
+    gradient buffer in two buckets (dp.plan_parameters(late=...), pack("early") / finish_backward / pack("late")).  Same kernels
+    in the same order: every gradient bit-identical to the one-message step; the late bucket holds exactly the input layers."""
+    from analysisgnn_amd import dp, graph
+    from analysisgnn_amd.heads import MultiTaskLoss, training_loss
+    from analysisgnn_amd.models import TorchAnalysisGNN
+    from analysisgnn_amd.synth import make_sampled_batch, torch_inputs
+    dev = torch.device("cuda", 0)
+    tasks = {"cadence": 4, "localkey": 50, "hrythm": 2}
+    g = make_sampled_batch(4, 500, (5, 5), first_seed=3)
+    I = torch_inputs(g, 25, dev, seed=0)
+    labels = torch.stack([torch.randint(0, c, (I["batch_size"],), generator=torch.Generator().manual_seed(i)).to(dev)
+                          for i, c in enumerate(tasks.values())])
+    torch.manual_seed(0)
+    model = TorchAnalysisGNN(g.metadata(), 25, 256, 128, tasks, 3, dropout=0.0, use_jk=False, logit_fusion=False).to(dev).train()
+    clf = MultiTaskLoss(list(tasks)).to(dev)
+    both = torch.nn.ModuleDict({"m": model, "c": clf})
+    was = graph.index_cache_enabled
+    graph.index_cache_enabled = False
+    dp.enable_wgrad_overlap(True, "sequence")
+    dp.defer_weight_grads(True)
+
+    def run(split):
+        model.split_backward = split
+        late = model.late_parameters() if split else []
+        params, tight = dp.plan_parameters(both, late=late)
+        flat = dp.FlatGradBuffer(params, views=False, tight=tight, late=late)
+        flat.zero()
+        x = model.encode(I["pitch_spelling"], I["key_signature"], I["x_dict"], I["edge_index_dict"], I["batch_dict"], I["batch_size"],
+                         I["neighbor_mask_node"], I["neighbor_mask_edge"])
+        logits, offs, _ = model.forward_clf_fused(x)
+        loss, _ = training_loss(logits, offs, labels, x, 0.1, 0.1, -1, task_params=clf.weights())
+        loss.backward()
+        if split:
+            assert all(p.grad is None for p in late) and sum(p.grad is not None for p in params) > 50
+            work = flat.all_reduce_early_async()
+            assert work is None                                   # one rank: nothing to ship
+            model.finish_backward()
+            flat.all_reduce_late_and_finish(work)
+            assert flat.cut == flat.flat.numel() - sum((p.numel() + 3) // 4 * 4 for p in late)
+        else:
+            flat.all_reduce_mean()
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().clone() for n, p in both.named_parameters()}, float(loss)
+    try:
+        g0, l0 = run(False)
+        g1, l1 = run(True)
+        assert l0 == l1
+        for n in g0:
+            assert torch.equal(g0[n], g1[n]), n
+    finally:
+        model.split_backward = False
+        dp.defer_weight_grads(False)
+        dp.enable_wgrad_overlap(False)
+        graph.index_cache_enabled = was
