@@ -199,3 +199,40 @@ def test_scatter_surface(reduce, with_out):
     if with_out:
         assert_close(og.grad, oc.grad, 1e-5, "dout")
     assert S.scatter_add is S.scatter_sum and callable(S.scatter_mean)
+
+
+def test_scatter_is_a_registered_op_and_traces_without_a_graph_break():
+    """the reference may wrap the model in torch.compile(dynamic=True) (train/train_analysisgnn.py:202-203) — custom
+    ops must be registered or break the graph cleanly.  `analysisgnn_amd::scatter_reduce` carries a fake (meta) kernel and an
+    autograd formula: torch.library.opcheck passes, and a SageConvScatter-shaped function (core/gnn.py:62-76) compiles with
+    fullgraph=True (any graph break raises) and gives the eager values and gradients."""
+    from analysisgnn_amd import scatter as S
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(2)
+    n, e, w = 50, 180, 16
+    x = torch.randn(n, w, generator=g).to(dev)
+    wt = (torch.randn(w, w, generator=g) * 0.3).to(dev)
+    idx = torch.randint(0, n, (2, e), generator=g).to(dev)
+    for mean in (False, True):
+        src = torch.randn(e, w, device=dev, requires_grad=True)
+        out0 = torch.randn(n, w, device=dev, requires_grad=True)
+        torch.library.opcheck(S._scatter_op, (src, idx[0], out0, n, mean))
+        torch.library.opcheck(S._scatter_op, (src, idx[0], None, n, mean))
+
+    def layer(x, wt, idx):
+        h = x @ wt
+        s = S.scatter(h[idx[1]], idx[0], 0, out=h.clone(), reduce="mean")
+        return torch.cat([x, s], dim=-1).relu()
+
+    xe = x.clone().requires_grad_(True)
+    we = wt.clone().requires_grad_(True)
+    ref = layer(xe, we, idx)
+    ref.sum().backward()
+    xc = x.clone().requires_grad_(True)
+    wc = wt.clone().requires_grad_(True)
+    compiled = torch.compile(layer, fullgraph=True, dynamic=True, backend="aot_eager")
+    out = compiled(xc, wc, idx)
+    out.sum().backward()
+    assert_close(out, ref, 1e-6, "compiled forward")
+    assert_close(xc.grad, xe.grad, 1e-5, "compiled dx")
+    assert_close(wc.grad, we.grad, 1e-5, "compiled dw")
