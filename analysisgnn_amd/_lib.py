@@ -114,6 +114,8 @@ SIGNATURES = {
     "agnn_relt_dw_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int64]),
     "agnn_relt_dw_f32": (C.c_int, [C.c_int, C.POINTER(ReltItem), C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_size_t,
                                   C.c_void_p]),
+    "agnn_gemm_nt_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
+                                   C.c_int64, C.c_void_p]),
     "agnn_absdiff_fwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
                                        C.c_void_p]),
     "agnn_absdiff_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,

@@ -48,9 +48,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(GemmArgs g) {
 
   // global -> LDS staging: thread t moves rows (t / 4) and 64 + (t / 4), k offset 4 * (t % 4), of both operands
   const int sr = tid >> 2, sk = 4 * (tid & 3);
-  const int ar0 = min(row0 + sr, g.M - 1), ar1 = min(row0 + 64 + sr, g.M - 1);          // rows past M: clamped, never stored
-  const float* pa0 = g.a + static_cast<int64_t>(ar0) * g.ld_a + sk;
-  const float* pa1 = g.a + static_cast<int64_t>(ar1) * g.ld_a + sk;
+  const float* pa0 = g.a + static_cast<int64_t>(min(row0 + sr, g.M - 1)) * g.ld_a + sk;          // rows past M: clamped, never stored
+  const float* pa1 = g.a + static_cast<int64_t>(min(row0 + 64 + sr, g.M - 1)) * g.ld_a + sk;
   const float* pw0 = g.w + static_cast<int64_t>(col0 + sr) * g.ld_w + sk;
   const float* pw1 = g.w + static_cast<int64_t>(col0 + 64 + sr) * g.ld_w + sk;
   const int so0 = sr * LDT + sk, so1 = (64 + sr) * LDT + sk;
@@ -62,6 +61,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(GemmArgs g) {
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0};
 
   const int nk = g.K / BK;
+  // One step ahead: while step kb is multiplied out of LDS buffer kb & 1, the operands of step kb + 1 are requested into
+  // registers and written to the other buffer at the end of the step.  Straight-line code on named registers: the same loop
+  // written with a staging struct passed to lambdas put the struct in scratch memory and ran at 68 TFLOP/s instead of 96, as did
+  // a two-steps-ahead variant (profiles/r03_gemm.md).
   float4 ra0 = *reinterpret_cast<const float4*>(pa0), ra1 = *reinterpret_cast<const float4*>(pa1);
   float4 rw0 = *reinterpret_cast<const float4*>(pw0), rw1 = *reinterpret_cast<const float4*>(pw1);
   *reinterpret_cast<float4*>(&sA[0][so0]) = ra0;

@@ -275,6 +275,15 @@ int agnn_gated_bwd_src_f32(const agnn_gated_t* g /* (host) */, const float* ds, 
                            float* dh, agnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * fp32 projection GEMM on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32):  C[M, N] = A[M, K] * W[N, K]^T (+ bias[N])
+ * — `nn.Linear` / PyG SAGEConv's lin_l, lin_r on a tall activation matrix (ref: models/cadence.py:147-159, core/gnn.py:65,75).
+ * Both operands K-contiguous; N % 128 == 0, K % 16 == 0, 16-byte aligned rows (ld % 4 == 0).  The input-gradient product
+ * dX = dY * W is the same call with the TRANSPOSED weight as `w` (N := in_features, K := out_features).
+ * ------------------------------------------------------------------------------------------ */
+int agnn_gemm_nt_f32(const float* a, int64_t ld_a, const float* w, int64_t ld_w, const float* bias, int64_t M, int32_t N,
+                     int32_t K, float* c, int64_t ld_c, agnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Aggregation side of the in-tree RelEdgeConv (ref: models/core/gnn.py:99-105: m_ij = W_e [h_j || |h_i - h_j|] + b_e scattered
  * with mean onto row i).  W_e is linear, so sum_j m_ij = W_e [S_i || D_i] + deg_i b_e with the two per-row aggregates
  *     S_i = sum_{p in row i} h_col[p] ,    D_i = sum_{p in row i} |h_i - h_col[p]|

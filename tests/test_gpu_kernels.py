@@ -298,3 +298,24 @@ def test_multitask_ce_uncovered_columns_and_ignored_rows():
     (ref * torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64)).sum().backward()
     assert torch.allclose(loss.cpu().double(), ref.detach(), rtol=1e-5, atol=1e-6)
     assert torch.allclose(logits.grad.cpu().double(), ref_in.grad, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(300, 128, 16, True), (1000, 256, 160, False), (16335, 256, 1280, True), (129, 384, 48, True)])
+def test_gemm_nt_matches_float64(M, N, K, bias):
+    """agnn_gemm_nt_f32 (hand-written fp32 MFMA projection GEMM: C = A W^T + b) against float64, incl. a row count that is not
+    a multiple of the 128-row tile, strided operands and the C2 SAGE-layer shape.  Exact-fp32 MFMA: ~1e-6 relative."""
+    from analysisgnn_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    a_full = torch.randn(M, K + 8, generator=g).to(DEV)
+    a = a_full[:, :K]                                            # leading dimension > K
+    w = (torch.randn(N, K, generator=g) * 0.1).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV) if bias else None
+    c = torch.full((M, N + 4), 7.0, device=DEV)
+    _lib.check(lib.agnn_gemm_nt_f32(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _lib.ptr(b), M, N, K, c.data_ptr(), c.stride(0),
+                                    _lib.stream_ptr(torch.device(DEV))), "agnn_gemm_nt_f32")
+    ref = a.double() @ w.double().t() + (b.double() if bias else 0.0)
+    err = float((c[:, :N].double() - ref).abs().max() / ref.abs().max())
+    assert err < 5e-6, err
+    assert float((c[:, N:] - 7.0).abs().max()) == 0.0            # nothing written past N
+    assert lib.agnn_gemm_nt_f32(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), None, M, N + 1, K, c.data_ptr(), c.stride(0), None) < 0
