@@ -306,6 +306,7 @@ def test_gemm_nt_matches_float64(M, N, K, bias):
     a multiple of the 128-row tile, strided operands and the C2 SAGE-layer shape.  Exact-fp32 MFMA: ~1e-6 relative."""
     from analysisgnn_amd import _lib
     lib = _lib.load()
+    DEV = "cuda:0"
     g = torch.Generator().manual_seed(M + N + K)
     a_full = torch.randn(M, K + 8, generator=g).to(DEV)
     a = a_full[:, :K]                                            # leading dimension > K
