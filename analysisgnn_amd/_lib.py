@@ -36,7 +36,7 @@ ROWEND_MAX_ITEMS = 64
 class Sampler(C.Structure):
     _fields_ = [("n_rel", C.c_int32), ("rowptr", C.c_void_p * 8), ("col", C.c_void_p * 8), ("win_start", C.c_void_p),
                 ("n_sub", C.c_int32), ("n_targets", C.c_int32), ("n_hops", C.c_int32), ("fan", C.c_int32 * 4), ("cap", C.c_int32 * 4),
-                ("rng", C.c_void_p), ("node_gid", C.c_void_p), ("edges", C.c_void_p * 8), ("e_cap", C.c_int64), ("status", C.c_void_p), ("drops", C.c_void_p)]
+                ("rng", C.c_void_p), ("node_gid", C.c_void_p), ("edges", C.c_void_p * 8), ("e_cap", C.c_int64), ("status", C.c_void_p), ("drops", C.c_void_p), ("kept", C.c_void_p)]
 
 
 class ReltItem(C.Structure):
@@ -105,8 +105,10 @@ SIGNATURES = {
     "agnn_sampler_num_nodes": (C.c_int64, [C.POINTER(Sampler)]),
     "agnn_sampler_edge_capacity": (C.c_int64, [C.POINTER(Sampler)]),
     "agnn_sample_hops": (C.c_int, [C.POINTER(Sampler), C.c_void_p]),
-    "agnn_sample_members": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
-                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "agnn_sample_members": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                      C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "agnn_sample_compact_nodes": (C.c_int64, [C.POINTER(Sampler), C.POINTER(C.c_int32)]),
+    "agnn_sample_compact": (C.c_int, [C.POINTER(Sampler), C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_void_p]),
     "agnn_gather_rows_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "agnn_gather_i64": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "agnn_relt_fwd_f32": (C.c_int, [C.c_int, C.POINTER(ReltItem), C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),

@@ -89,7 +89,11 @@ class DeviceSampler:
     graph replays it); `batch` is the dict `TorchAnalysisGNN.encode` consumes (the keys of `synth.torch_inputs`)."""
 
     def __init__(self, store: ScoreStore, n_sub: int, n_targets: int = 500, num_neighbors: Sequence[int] = (5, 5),
-                 capacity: Sequence[int] = (64, 64), seed: int = 0, group_capacity: Optional[Dict[str, int]] = None):
+                 capacity: Sequence[int] = (64, 64), seed: int = 0, group_capacity: Optional[Dict[str, int]] = None,
+                 pool: Optional[Sequence[int]] = None):
+        """`capacity[h]`: new nodes a subgraph may add in hop h.  `pool[h]` (optional): the batch-wide number of slots of hop h —
+        subgraphs rarely fill their capacity, so the padded blocks (n_sub x capacity[h] rows each) are squeezed into pools by a
+        second launch (`agnn_sample_compact`): fewer padding rows through every layer, the shapes stay static."""
         if len(capacity) != len(num_neighbors):
             raise ValueError("one capacity per hop")
         self.store, self.n_sub, self.n_targets = store, int(n_sub), int(n_targets)
@@ -109,7 +113,10 @@ class DeviceSampler:
             raise _lib.AgnnError("bad sampler configuration")
         self.win_start = torch.zeros(self.n_sub, dtype=torch.int32, device=dev)
         self.rng = torch.tensor([int(seed), 0], dtype=torch.int64, device=dev)       # (seed, step): bump step per batch
-        self.node_gid = torch.empty(self.num_nodes, dtype=torch.int32, device=dev)
+        self.pool = [int(v) for v in pool] if pool is not None else None
+        if self.pool is not None and len(self.pool) != len(self.cap):
+            raise ValueError("one pool size per hop")
+        self.node_gid = torch.empty(self.num_nodes, dtype=torch.int32, device=dev)     # what agnn_sample_hops writes (padded blocks)
         self.edges = {et: torch.empty((2, self.e_cap), dtype=torch.int64, device=dev) for et in store.edge_types}
         cfg.win_start, cfg.rng, cfg.node_gid = self.win_start.data_ptr(), self.rng.data_ptr(), self.node_gid.data_ptr()
         for r, et in enumerate(store.edge_types):
@@ -121,14 +128,27 @@ class DeviceSampler:
         self._cfg = cfg
         B, T = self.n_sub, self.n_targets
         self.batch_size = B * T
-        # static per-hop capacities = what trim_to_layer is driven by (PyG num_sampled_nodes / num_sampled_edges)
-        self.num_sampled_nodes = {"note": [B * T] + [B * c for c in self.cap]}
+        blocks = [B * c for c in self.cap]
+        if self.pool is not None:
+            self._kept = torch.zeros(len(self.cap) * B, dtype=torch.int32, device=dev)
+            cfg.kept = self._kept.data_ptr()
+            self._pool_arr = (_lib.C.c_int32 * len(self.pool))(*self.pool)
+            n_pool = int(lib.agnn_sample_compact_nodes(cfg, self._pool_arr))
+            if n_pool < 0:
+                raise _lib.AgnnError("bad pool configuration")
+            self._gid_padded, self.num_nodes = self.node_gid, n_pool
+            self.node_gid = torch.empty(n_pool, dtype=torch.int32, device=dev)          # pool layout: what everything downstream reads
+            blocks = list(self.pool)
+        # static per-hop block sizes = what trim_to_layer is driven by (PyG num_sampled_nodes / num_sampled_edges)
+        self.num_sampled_nodes = {"note": [B * T] + blocks}
         e_per_hop, F = [], T
         for f, c in zip(self.fan, self.cap):
             e_per_hop.append(B * F * f)
             F = c
         self.num_sampled_edges = {et: list(e_per_hop) for et in store.edge_types}
         sub = [np.repeat(np.arange(B), T)] + [np.repeat(np.arange(B), c) for c in self.cap]
+        if self.pool is not None:                     # rewritten by every sample(): which subgraph a pool slot serves
+            sub = [sub[0], np.zeros(sum(self.pool), dtype=np.int64)]
         self.batch_note = torch.from_numpy(np.concatenate(sub).astype(np.int64)).to(dev)
         self.batch_note.agnn_target_lengths = [T] * B
         self.x = torch.empty((self.num_nodes, store.x.shape[1]), dtype=torch.float32, device=dev)
@@ -147,7 +167,7 @@ class DeviceSampler:
             self.edges[et] = torch.empty((2, self.num_nodes), dtype=torch.int64, device=dev)
             self.group_x[t] = torch.empty((B * cg, store.group_x[t].shape[1]), dtype=torch.float32, device=dev)
             self.num_sampled_nodes[t] = [B * cg] + [0] * len(self.cap)
-            self.num_sampled_edges[et] = [B * T + (B * self.cap[0] if self.cap else 0)] + [B * c for c in self.cap[1:]]
+            self.num_sampled_edges[et] = [B * T + (blocks[0] if blocks else 0)] + blocks[1:]
             x_dict[t] = self.group_x[t][:, :store.in_channels]
             batch_dict[t] = torch.from_numpy(np.repeat(np.arange(B), cg).astype(np.int64)).to(dev)
         self.batch = dict(
@@ -192,6 +212,9 @@ class DeviceSampler:
         st = _lib.stream_ptr(dev)
         self.rng[1:2].add_(1)
         _lib.check(lib.agnn_sample_hops(self._cfg, st), "agnn_sample_hops")
+        if self.pool is not None:
+            _lib.check(lib.agnn_sample_compact(self._cfg, self._pool_arr, self.node_gid.data_ptr(), self.batch_note.data_ptr(), st),
+                       "agnn_sample_compact")
         s = self.store
         _lib.check(lib.agnn_gather_rows_f32(s.x.data_ptr(), s.x.stride(0), self.node_gid.data_ptr(), self.num_nodes, s.x.shape[1],
                                             self.x.data_ptr(), self.x.stride(0), st), "agnn_gather_rows_f32")
@@ -199,7 +222,9 @@ class DeviceSampler:
                                        self.attrs.data_ptr(), self.attrs.stride(0), st), "agnn_gather_i64")
         for t in s.group_types:          # + two launches per metrical type: members, their feature rows
             cg = self.group_cap[t]
-            _lib.check(lib.agnn_sample_members(self.node_gid.data_ptr(), self.num_nodes, s.group_of[t].data_ptr(), self.win_start.data_ptr(),
+            _lib.check(lib.agnn_sample_members(self.node_gid.data_ptr(), self.num_nodes,
+                                               self.batch_note.data_ptr() if self.pool is not None else None,
+                                               s.group_of[t].data_ptr(), self.win_start.data_ptr(),
                                                self.n_sub, self.n_targets, len(self.cap), self._cap_arr, cg, self.group_gid[t].data_ptr(),
                                                self.edges[("note", "connects", t)].data_ptr(), self.drops.data_ptr(), st), "agnn_sample_members")
             gx = s.group_x[t]

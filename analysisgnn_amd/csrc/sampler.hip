@@ -169,6 +169,7 @@ __global__ __launch_bounds__(kThreads) void k_sample_hops(SamplerArgs A) {
     }
     const int kept = listed < cap ? listed : cap;
     if (tid == 0 && n_new > kept) n_drop += n_new - kept;
+    if (tid == 0 && c.kept != nullptr) c.kept[h * c.n_sub + s] = kept;                   // for agnn_sample_compact
     for (int i = tid; i < cap; i += kThreads) {
       const int g = i < kept ? newl[i] : -1;
       c.node_gid[nbase + static_cast<int64_t>(s) * cap + i] = g;
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(kThreads) void k_sample_hops(SamplerArgs A) {
 // Notes are sorted by onset, so the groups a window's target notes belong to form ONE contiguous id range
 // [group_of[w], group_of[w + T - 1]]: no set, no sort.  Thread i: group slot i (i < n_sub * cap_g) and note slot i (i < n_nodes).
 struct MemberArgs {
+  const int64_t* batch;      // optional: subgraph id per note slot (pool layout); NULL = the padded hop-block layout
   const int32_t* node_gid;
   const int32_t* group_of;
   const int32_t* win_start;
@@ -255,7 +257,9 @@ __global__ __launch_bounds__(256) void k_sample_members(MemberArgs a) {
   if (idx < a.n_nodes) {
     int s;
     int64_t base = static_cast<int64_t>(a.n_sub) * a.n_targets;
-    if (idx < base) {
+    if (a.batch != nullptr) {
+      s = static_cast<int>(a.batch[idx]);
+    } else if (idx < base) {
       s = static_cast<int>(idx / a.n_targets);
     } else {
       s = 0;
@@ -278,6 +282,101 @@ __global__ __launch_bounds__(256) void k_sample_members(MemberArgs a) {
     }
     a.edges[idx] = src;
     a.edges[a.n_nodes + idx] = dst;
+  }
+}
+
+// ---- agnn_sample_compact: the padded hop blocks [n_sub x cap[h]] of a sampled batch squeezed into pools of pool[h] slots --------
+// Subgraph s's kept nodes of hop h move to  pool_base[h] + (sum of kept[h][s'] over s' < s) + i  — subgraph order, rank order:
+// still hop-ordered, a subgraph's nodes still contiguous.  Every workgroup scans the kept counts itself (n_sub x n_hops small
+// integers); then a grid-stride pass moves node ids, writes the subgraph id of every pool slot and rewrites BOTH endpoints of
+// every edge slot in place (an edge whose endpoint fell past the pool's end becomes (-1, -1)).
+struct CompactArgs {
+  const int32_t* kept;       // [n_hops][n_sub]
+  const int32_t* gid_in;     // padded layout
+  int32_t* gid_out;          // pool layout
+  int64_t* batch_out;        // [n_out]
+  int64_t* edges[AGNN_SAMPLER_MAX_REL];
+  int32_t* drops;
+  int64_t e_cap;
+  int32_t n_rel, n_sub, n_targets, n_hops;
+  int32_t cap[AGNN_SAMPLER_MAX_HOPS], pool[AGNN_SAMPLER_MAX_HOPS];
+};
+
+constexpr int kCompactMaxSub = 1024;   // n_sub * n_hops offsets in LDS
+
+__global__ __launch_bounds__(256) void k_sample_compact(CompactArgs a) {
+  __shared__ int s_off[kCompactMaxSub];      // exclusive prefix of min(kept, room) per hop
+  __shared__ int s_keep[kCompactMaxSub];     // nodes of (h, s) that found room in the pool
+  __shared__ int s_tot[AGNN_SAMPLER_MAX_HOPS];
+  const int B = a.n_sub, T = a.n_targets;
+  if (threadIdx.x < a.n_hops) {
+    const int h = threadIdx.x;
+    int run = 0, lost = 0;
+    for (int s = 0; s < B; ++s) {
+      const int k = a.kept[h * B + s];
+      const int room = a.pool[h] - run;
+      const int take = k < room ? k : (room > 0 ? room : 0);
+      s_off[h * B + s] = run;
+      s_keep[h * B + s] = take;
+      run += take;
+      lost += k - take;
+    }
+    s_tot[h] = run;
+    if (lost > 0 && blockIdx.x == 0 && a.drops != nullptr) atomicAdd(a.drops, lost);
+  }
+  __syncthreads();
+  const int64_t n_tgt = static_cast<int64_t>(B) * T;
+  int64_t n_in = n_tgt, n_out = n_tgt;
+  for (int h = 0; h < a.n_hops; ++h) { n_in += static_cast<int64_t>(B) * a.cap[h]; n_out += a.pool[h]; }
+  auto remap = [&](int64_t id) -> int64_t {
+    if (id < n_tgt) return id;                       // targets (and -1) stay
+    int64_t base = n_tgt, pbase = n_tgt;
+    for (int h = 0; h < a.n_hops; ++h) {
+      const int64_t blk = static_cast<int64_t>(B) * a.cap[h];
+      if (id < base + blk) {
+        const int s = static_cast<int>((id - base) / a.cap[h]), i = static_cast<int>((id - base) - static_cast<int64_t>(s) * a.cap[h]);
+        return i < s_keep[h * B + s] ? pbase + s_off[h * B + s] + i : -1;
+      }
+      base += blk;
+      pbase += a.pool[h];
+    }
+    return -1;
+  };
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+  const int64_t t0 = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  // nodes: targets copy through; pool slots default to padding, then the kept nodes land on theirs
+  for (int64_t j = t0; j < n_out; j += stride) {
+    if (j < n_tgt) {
+      a.gid_out[j] = a.gid_in[j];
+      a.batch_out[j] = j / T;
+    } else {
+      int64_t pbase = n_tgt;
+      int h = 0;
+      while (h + 1 < a.n_hops && j >= pbase + a.pool[h]) { pbase += a.pool[h]; ++h; }
+      if (j - pbase >= s_tot[h]) { a.gid_out[j] = -1; a.batch_out[j] = B - 1; }     // unused pool slot: no features, no edges
+    }
+  }
+  for (int64_t j = t0 + n_tgt; j < n_in; j += stride) {
+    const int64_t nj = remap(j);
+    if (nj >= 0) {
+      int64_t base = n_tgt;
+      int h = 0;
+      while (j >= base + static_cast<int64_t>(B) * a.cap[h]) { base += static_cast<int64_t>(B) * a.cap[h]; ++h; }
+      a.gid_out[nj] = a.gid_in[j];
+      a.batch_out[nj] = (j - base) / a.cap[h];
+    }
+  }
+  for (int r = 0; r < a.n_rel; ++r) {
+    int64_t* e0 = a.edges[r];
+    int64_t* e1 = e0 + a.e_cap;
+    for (int64_t e = t0; e < a.e_cap; e += stride) {
+      const int64_t s0 = e0[e], d0 = e1[e];
+      if (s0 < n_tgt && d0 < n_tgt) continue;          // both ends targets or the slot is empty: nothing moves
+      const int64_t s1 = remap(s0), d1 = remap(d0);
+      const bool ok = s1 >= 0 && d1 >= 0;
+      e0[e] = ok ? s1 : -1;
+      e1[e] = ok ? d1 : -1;
+    }
   }
 }
 
@@ -347,9 +446,41 @@ extern "C" int agnn_sample_hops(const agnn_sampler_t* cfg, agnn_stream_t stream_
   return check_launch("sample_hops");
 }
 
-extern "C" int agnn_sample_members(const int32_t* node_gid, int64_t n_nodes, const int32_t* group_of, const int32_t* win_start,
-                                   int32_t n_sub, int32_t n_targets, int32_t n_hops, const int32_t* cap, int32_t cap_g,
-                                   int32_t* group_gid, int64_t* edges, int32_t* drops, agnn_stream_t stream_) {
+extern "C" int64_t agnn_sample_compact_nodes(const agnn_sampler_t* c, const int32_t* pool) {
+  if (!c || !pool) return -1;
+  int64_t n = static_cast<int64_t>(c->n_sub) * c->n_targets;
+  for (int h = 0; h < c->n_hops; ++h) n += pool[h];
+  return n;
+}
+
+extern "C" int agnn_sample_compact(const agnn_sampler_t* cfg, const int32_t* pool, int32_t* node_gid_out, int64_t* batch_out,
+                                   agnn_stream_t stream_) {
+  using namespace agnn;
+  if (!cfg || !pool || !node_gid_out || !batch_out) return fail(AGNN_EINVAL, "sample_compact: null argument");
+  const agnn_sampler_t& c = *cfg;
+  if (!c.kept || !c.node_gid) return fail(AGNN_EINVAL, "sample_compact: the sampler configuration must carry `kept` (agnn_sample_hops fills it)");
+  if (c.n_hops <= 0 || c.n_hops > AGNN_SAMPLER_MAX_HOPS || c.n_rel <= 0 || c.n_rel > AGNN_SAMPLER_MAX_REL || c.n_sub <= 0 ||
+      static_cast<int64_t>(c.n_sub) * c.n_hops > kCompactMaxSub)
+    return fail(AGNN_EINVAL, "sample_compact: n_sub=%d x n_hops=%d (at most %d counters)", c.n_sub, c.n_hops, kCompactMaxSub);
+  CompactArgs a{};
+  a.kept = c.kept; a.gid_in = c.node_gid; a.gid_out = node_gid_out; a.batch_out = batch_out; a.drops = c.drops; a.e_cap = c.e_cap;
+  a.n_rel = c.n_rel; a.n_sub = c.n_sub; a.n_targets = c.n_targets; a.n_hops = c.n_hops;
+  for (int h = 0; h < c.n_hops; ++h) {
+    if (pool[h] <= 0 || pool[h] > static_cast<int64_t>(c.n_sub) * c.cap[h]) return fail(AGNN_EINVAL, "sample_compact: pool[%d]=%d not in [1, n_sub * cap]", h, pool[h]);
+    a.cap[h] = c.cap[h];
+    a.pool[h] = pool[h];
+  }
+  for (int r = 0; r < c.n_rel; ++r) a.edges[r] = c.edges[r];
+  const int64_t work = c.e_cap > agnn_sampler_num_nodes(cfg) ? c.e_cap : agnn_sampler_num_nodes(cfg);
+  int64_t blocks = (work + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_sample_compact, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream_), a);
+  return check_launch("sample_compact");
+}
+
+extern "C" int agnn_sample_members(const int32_t* node_gid, int64_t n_nodes, const int64_t* batch, const int32_t* group_of,
+                                   const int32_t* win_start, int32_t n_sub, int32_t n_targets, int32_t n_hops, const int32_t* cap,
+                                   int32_t cap_g, int32_t* group_gid, int64_t* edges, int32_t* drops, agnn_stream_t stream_) {
   using namespace agnn;
   if (n_sub <= 0 || n_targets <= 0 || cap_g <= 0 || n_hops < 0 || n_hops > AGNN_SAMPLER_MAX_HOPS || (n_hops > 0 && !cap))
     return fail(AGNN_EINVAL, "sample_members: n_sub=%d n_targets=%d n_hops=%d cap_g=%d", n_sub, n_targets, n_hops, cap_g);
@@ -360,9 +491,10 @@ extern "C" int agnn_sample_members(const int32_t* node_gid, int64_t n_nodes, con
     a.cap[h] = cap[h];
     expect += static_cast<int64_t>(n_sub) * cap[h];
   }
-  if (n_nodes != expect) return fail(AGNN_EINVAL, "sample_members: n_nodes=%lld, the hop layout has %lld slots", (long long)n_nodes, (long long)expect);
+  if (batch == nullptr && n_nodes != expect) return fail(AGNN_EINVAL, "sample_members: n_nodes=%lld, the hop layout has %lld slots", (long long)n_nodes, (long long)expect);
+  if (batch != nullptr && (n_nodes < static_cast<int64_t>(n_sub) * n_targets || n_nodes > expect)) return fail(AGNN_EINVAL, "sample_members: n_nodes=%lld outside the pool layout's range", (long long)n_nodes);
   if (!node_gid || !group_of || !win_start || !group_gid || !edges) return fail(AGNN_EINVAL, "sample_members: null argument");
-  a.node_gid = node_gid; a.group_of = group_of; a.win_start = win_start; a.group_gid = group_gid; a.edges = edges; a.drops = drops;
+  a.batch = batch; a.node_gid = node_gid; a.group_of = group_of; a.win_start = win_start; a.group_gid = group_gid; a.edges = edges; a.drops = drops;
   a.n_nodes = n_nodes; a.n_sub = n_sub; a.n_targets = n_targets; a.n_hops = n_hops; a.cap_g = cap_g;
   const int64_t work = n_nodes > static_cast<int64_t>(n_sub) * cap_g ? n_nodes : static_cast<int64_t>(n_sub) * cap_g;
   hipLaunchKernelGGL(k_sample_members, dim3(static_cast<unsigned>((work + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), a);

@@ -305,7 +305,10 @@ def main():
         for sg in scores:                                           # C3's relation set: the types whose source is a note
             sg.edge_index = {et: e for et, e in sg.edge_index.items() if et[0] == "note"}
         store = ScoreStore(scores, IN_CH, dev, tasks=tasks, seed=0)
-        sampler = DeviceSampler(store, N_SUB, N_NOTES, (5,) * (layers - 1), (32,) * (layers - 1), seed=1 + rank)
+        # per-subgraph capacity 32 new notes per hop, batch-wide pools of 8 per subgraph (a window of consecutive notes adds a few:
+        # measured ~2.7 per subgraph and hop on this corpus; overflow is counted in sampler.dropped(), reported below)
+        sampler = DeviceSampler(store, N_SUB, N_NOTES, (5,) * (layers - 1), (32,) * (layers - 1), seed=1 + rank,
+                                pool=(8 * N_SUB,) * (layers - 1))
         g_meta = sampler.metadata()
         win_rng = np.random.default_rng(100 + rank)
         sampler.set_windows(store.random_windows(N_SUB, N_NOTES, win_rng))
@@ -510,6 +513,8 @@ def main():
                                    + ("hipGraph replay" if graphs is not None else "EAGER launches (see \"graph\")"),
                        "workload_id": args.workload, "per_gpu_subgraphs": N_SUB, "target_notes_per_subgraph": N_NOTES,
                        "objective": args.mt_strategy,
+                       **({"sampler": {"capacity_per_subgraph": sampler.cap, "pool": sampler.pool, "rows": sampler.num_nodes,
+                                       "sources_dropped_by_capacity_or_pool": sampler.dropped()}} if sampler is not None else {}),
                        "sharding": ("every rank draws its own windows from the replicated corpus" if sampler is not None
                                     else "rank r takes subgraphs {i : i mod G = r}"),
                        "parallelism": f"dp{world}",

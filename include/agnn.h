@@ -496,6 +496,7 @@ typedef struct {
   int64_t e_cap;                                 /* = agnn_sampler_edge_capacity */
   int32_t* status;                               /* (device) int32[1] or NULL: errors (agnn_check_status) */
   int32_t* drops;                                /* (device) int32[1] or NULL: sources cut by cap[h] (statistic) */
+  int32_t* kept;                                 /* (device) int32[n_hops * n_sub] or NULL: nodes kept per (hop, subgraph) */
 } agnn_sampler_t;
 int64_t agnn_sampler_num_nodes(const agnn_sampler_t* cfg /* (host) */);
 int64_t agnn_sampler_edge_capacity(const agnn_sampler_t* cfg /* (host) */);
@@ -511,9 +512,19 @@ int agnn_sample_hops(const agnn_sampler_t* cfg /* (host) */, agnn_stream_t strea
  *                               range, else (-1, -1).  Slot order = node order, so the per-hop edge counts that drive
  *                               trim_to_layer are [n_sub*(n_targets + cap[0]), n_sub*cap[1], ...]: an edge is trimmed with
  *                               its source note's hop block; the group nodes themselves are all hop-0 (never trimmed). */
-int agnn_sample_members(const int32_t* node_gid, int64_t n_nodes, const int32_t* group_of, const int32_t* win_start,
-                        int32_t n_sub, int32_t n_targets, int32_t n_hops, const int32_t* cap /* (host) [n_hops] */,
-                        int32_t cap_g, int32_t* group_gid, int64_t* edges, int32_t* drops, agnn_stream_t stream);
+int agnn_sample_members(const int32_t* node_gid, int64_t n_nodes, const int64_t* batch /* NULL, or (pool layout) subgraph id per slot */,
+                        const int32_t* group_of, const int32_t* win_start, int32_t n_sub, int32_t n_targets, int32_t n_hops,
+                        const int32_t* cap /* (host) [n_hops] */, int32_t cap_g, int32_t* group_gid, int64_t* edges, int32_t* drops,
+                        agnn_stream_t stream);
+/* The padded hop blocks [n_sub x cap[h]] squeezed into batch-wide POOLS of pool[h] <= n_sub * cap[h] slots (a subgraph rarely
+ * fills its capacity: at C2 170 of 2 048 slots are used): subgraph s's kept nodes of hop h move to
+ * pool_base[h] + sum_{s' < s} kept[h][s'] + rank — still hop-ordered, still static shapes (trim counts = the pool sizes), a
+ * subgraph's nodes still contiguous.  Run after agnn_sample_hops with the same configuration (`kept` set): writes the node ids
+ * in pool layout (agnn_sample_compact_nodes slots) and the subgraph id of every slot, and rewrites the endpoints of every edge
+ * slot IN PLACE; nodes past a pool's end are dropped with their edges and counted in `drops`. */
+int64_t agnn_sample_compact_nodes(const agnn_sampler_t* cfg /* (host) */, const int32_t* pool /* (host) [n_hops] */);
+int agnn_sample_compact(const agnn_sampler_t* cfg /* (host) */, const int32_t* pool /* (host) [n_hops] */, int32_t* node_gid_out,
+                        int64_t* batch_out, agnn_stream_t stream);
 int agnn_gather_rows_f32(const float* src, int64_t ld_src, const int32_t* gid, int64_t n, int32_t H, float* out,
                          int64_t ld_out, agnn_stream_t stream);
 int agnn_gather_i64(const int64_t* src, int64_t ld_src, const int32_t* gid, int64_t n, int32_t n_vec, int64_t fill,

@@ -143,3 +143,38 @@ def sample_members(node_gid: np.ndarray, group_of: np.ndarray, win_start: Sequen
                     edges[0, slot] = slot
                     edges[1, slot] = s * cap_g + (gg - gmin)
     return group_gid, edges, dropped
+
+
+def compact(node_gid: np.ndarray, edges: Sequence[np.ndarray], n_sub: int, n_targets: int, cap: Sequence[int], pool: Sequence[int]):
+    """CPU restatement of `agnn_sample_compact`: the padded hop blocks squeezed into batch-wide pools.
+    -> (node_gid_pool int32, edges (remapped copies), batch int64 [n_out], dropped)."""
+    B, T = int(n_sub), int(n_targets)
+    n_tgt = B * T
+    n_out = n_tgt + sum(pool)
+    gid = np.full(n_out, -1, dtype=np.int32)
+    batch = np.full(n_out, B - 1, dtype=np.int64)
+    gid[:n_tgt] = node_gid[:n_tgt]
+    batch[:n_tgt] = np.arange(n_tgt) // T
+    new_id = np.full(node_gid.shape[0] + 1, -1, dtype=np.int64)       # last entry: the image of -1
+    new_id[:n_tgt] = np.arange(n_tgt)
+    base, pbase, dropped = n_tgt, n_tgt, 0
+    for h, (c, p) in enumerate(zip(cap, pool)):
+        run = 0
+        for s in range(B):
+            blk = node_gid[base + s * c:base + (s + 1) * c]
+            k = int((blk >= 0).sum())
+            assert (blk[:k] >= 0).all()                               # kept nodes fill a block from the front
+            take = max(0, min(k, p - run))
+            gid[pbase + run:pbase + run + take] = blk[:take]
+            batch[pbase + run:pbase + run + take] = s
+            new_id[base + s * c:base + s * c + take] = pbase + run + np.arange(take)
+            run += take
+            dropped += k - take
+        base += B * c
+        pbase += p
+    out = []
+    for e in edges:
+        s1, d1 = new_id[e[0]], new_id[e[1]]                           # index -1 -> the sentinel
+        ok = (s1 >= 0) & (d1 >= 0)
+        out.append(np.stack([np.where(ok, s1, -1), np.where(ok, d1, -1)]))
+    return gid, out, batch, dropped

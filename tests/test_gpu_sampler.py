@@ -346,3 +346,65 @@ def test_hgt_on_the_padded_hetero_batch_equals_the_compact_batch():
     with torch.no_grad():
         ref = E.hybrid_hgt(P, "", md, 3, 4, xc, ei_c, bc, smp.batch_size, nodes_per_hop, edges_per_hop)
     assert_close(out, ref, 1e-4, "padded hetero batch vs compact batch")
+
+
+@pytest.mark.parametrize("hetero", [False, True])
+def test_pooled_batch_matches_oracle_and_the_padded_batch(hetero):
+    """agnn_sample_compact: the padded hop blocks squeezed into batch-wide pools — node ids, subgraph ids and remapped edge slots
+    bit for bit against oracle/sampler_ref.compact applied to the padded batch of the same windows / seed / step; the second
+    hop's pool is set too small on purpose (nodes past its end are dropped with their edges and counted).  With roomy pools the
+    encoder's target rows on the pooled batch equal those on the padded batch."""
+    from analysisgnn_amd import _lib
+    from analysisgnn_amd.batching import DeviceSampler
+    from analysisgnn_amd.encoders import HybridGNN
+    from oracle import sampler_ref as S
+    store, _ = _hetero_store() if hetero else _store()
+    B, T, fan, cap = 6, 200, (5, 5), (48, 48)
+    wins = store.random_windows(B, T, np.random.default_rng(6))
+    pad = DeviceSampler(store, B, T, fan, cap, seed=4)
+    pad.set_windows(wins)
+    bp = pad.sample()
+    torch.cuda.synchronize()
+    gid_p = pad.node_gid.cpu().numpy()
+    real = [int((gid_p[B * T + h * B * 48:B * T + (h + 1) * B * 48] >= 0).sum()) for h in range(2)]
+    for pool in ((real[0] + 7, max(real[1] - 5, 1)), (real[0] + 16, real[1] + 16)):
+        smp = DeviceSampler(store, B, T, fan, cap, seed=4, pool=pool)
+        smp.set_windows(wins)
+        b = smp.sample()
+        torch.cuda.synchronize()
+        n_rel = len(store.edge_types)
+        e_pad = [bp["edge_index_dict"][et].cpu().numpy() for et in store.edge_types]
+        gid, edges, batch, dropped = S.compact(gid_p, e_pad, B, T, cap, pool)
+        assert np.array_equal(smp.node_gid.cpu().numpy(), gid)
+        assert np.array_equal(b["batch_dict"]["note"].cpu().numpy(), batch)
+        for r, et in enumerate(store.edge_types):
+            assert np.array_equal(b["edge_index_dict"][et].cpu().numpy(), edges[r]), et
+        assert (dropped > 0) == (pool[1] < real[1]) and smp.dropped() >= dropped
+        assert b["neighbor_mask_node"]["note"] == [B * T, pool[0], pool[1]] and smp.num_nodes == B * T + sum(pool)
+        for t in store.group_types:                                   # membership edges on the pool layout
+            e = b["edge_index_dict"][("note", "connects", t)].cpu().numpy()
+            live = e[0] >= 0
+            assert np.array_equal(e[0][live], np.nonzero(live)[0]) and e.shape[1] == smp.num_nodes
+            assert np.array_equal(batch[e[0][live]], b["batch_dict"][t].cpu().numpy()[e[1][live]])
+            gof = store.group_of[t].cpu().numpy()
+            assert np.array_equal(gof[gid[e[0][live]]], smp.group_gid[t].cpu().numpy()[e[1][live]])
+            assert b["neighbor_mask_edge"][("note", "connects", t)] == [B * T + pool[0], pool[1]]
+    _lib.check_device_status(DEV)
+    if hetero:
+        return
+    # same subgraphs, two layouts: the encoder's target rows agree
+    H = 32
+    md = (["note"], store.edge_types)
+    torch.manual_seed(3)
+    m = HybridGNN(metadata=md, input_channels=H, hidden_channels=H, num_layers=3, dropout=0.0).to(DEV).eval()
+    feat = torch.randn(store.num_notes, H, generator=torch.Generator().manual_seed(5)).to(DEV)
+    outs = []
+    for s_, bb in ((pad, bp), (smp, b)):
+        g = s_.node_gid.long()
+        x = torch.where((g >= 0).unsqueeze(1), feat[g.clamp(min=0)], torch.zeros(1, H, device=DEV))
+        with torch.no_grad():
+            outs.append(m(x_dict={"note": x}, edge_index_dict={et: bb["edge_index_dict"][et] for et in store.edge_types},
+                          batch_dict={"note": bb["batch_dict"]["note"]}, batch_size=s_.batch_size,
+                          neighbor_mask_node={"note": bb["neighbor_mask_node"]["note"]},
+                          neighbor_mask_edge={et: bb["neighbor_mask_edge"][et] for et in store.edge_types}))
+    assert_close(outs[1], outs[0], 1e-5, "pooled vs padded batch")

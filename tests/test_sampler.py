@@ -123,3 +123,27 @@ def test_members_oracle_invariants():
         assert np.array_equal(ggid[edges[1][live]], group_of[node_gid[edges[0][live]]])
         assert (edges[1][~live] == -1).all() and (node_gid[~live & (np.arange(node_gid.size) < 2 * T)] >= 0).sum() == (0 if cap_g == 64 else (~live[:2 * T]).sum())
         assert (dropped > 0) == (cap_g == 10)
+
+
+def test_compact_oracle_invariants():
+    """sampler_ref.compact: hop order kept, a subgraph's nodes contiguous and in rank order, every live edge maps onto the same
+    global ids as before, nothing lost while the pools have room."""
+    _, _, rowptr, col = _store()
+    wins, T, fan, cap = [30, 700, 1500], 100, (5, 5), (40, 40)
+    gid, edges, _ = S.sample_hops(rowptr, col, wins, T, fan, cap, seed=3, step=2)
+    B = len(wins)
+    real = [int((gid[B * T + h * B * 40:B * T + (h + 1) * B * 40] >= 0).sum()) for h in range(2)]
+    pool = (real[0] + 3, real[1] + 3)
+    g2, e2, batch, dropped = S.compact(gid, edges, B, T, cap, pool)
+    assert dropped == 0 and g2.shape[0] == B * T + sum(pool)
+    assert sorted(g2[g2 >= 0].tolist()) == sorted(gid[gid >= 0].tolist())
+    for h in range(2):
+        blk = slice(B * T + sum(pool[:h]), B * T + sum(pool[:h + 1]))
+        b = batch[blk][g2[blk] >= 0]
+        assert (np.diff(b) >= 0).all()                          # subgraph order inside a pool
+    for e_old, e_new in zip(edges, e2):
+        live = e_old[0] >= 0
+        assert np.array_equal(live, e_new[0] >= 0)
+        assert np.array_equal(gid[e_old[0][live]], g2[e_new[0][live]]) and np.array_equal(gid[e_old[1][live]], g2[e_new[1][live]])
+    _, e3, _, dropped3 = S.compact(gid, edges, B, T, cap, (real[0], max(real[1] - 4, 1)))
+    assert dropped3 == min(4, real[1] - 1) and all((x[0] >= 0).sum() <= (y[0] >= 0).sum() for x, y in zip(e3, e2))
