@@ -389,7 +389,7 @@ def main():
     # With a process group in the process the NCCL watchdog thread issues HIP calls of its own; in the default (global) capture
     # error mode any such call from another thread invalidates a capture in progress.  thread_local confines the check to the
     # capturing thread (what torch's own DDP + CUDA-graph recipes use).  One-rank runs keep the stricter default.
-    cap_mode = "thread_local" if world > 1 else "global"
+    cap_mode = "thread_local" if (world > 1 or torch.distributed.is_initialized()) else "global"
     if not args.no_graph:
         try:
             side = torch.cuda.Stream(device=dev)
