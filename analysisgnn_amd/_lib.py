@@ -132,6 +132,12 @@ SIGNATURES = {
     "agnn_norm_act_bwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float,
                                         C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "agnn_skip_act_workspace_bytes": (C.c_size_t, []),
+    "agnn_skip_act_fwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_uint32,
+                                        C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "agnn_skip_act_bwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_uint32,
+                                        C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                        C.c_void_p, C.c_size_t, C.c_void_p]),
     "agnn_norm_act_colsum_f32": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "agnn_wgrad_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "agnn_wgrad_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,

@@ -46,7 +46,8 @@ __device__ __forceinline__ uint4 philox(uint4 c, uint2 k) {
   return c;
 }
 
-__device__ __forceinline__ float4 keep_mask(const NaArgs& a, int64_t row, int chunk_lane, float scale) {
+template <class Args>
+__device__ __forceinline__ float4 keep_mask(const Args& a, int64_t row, int chunk_lane, float scale) {
   const uint64_t seed = static_cast<uint64_t>(a.rng[0]), step = static_cast<uint64_t>(a.rng[1]);
   const uint64_t idx = static_cast<uint64_t>(row) * 256u + static_cast<uint32_t>(chunk_lane);     // one counter per float4
   const uint4 r = philox(make_uint4(static_cast<uint32_t>(idx), static_cast<uint32_t>(idx >> 32), a.call_id, static_cast<uint32_t>(step)),
@@ -285,6 +286,130 @@ __global__ __launch_bounds__(1024) void k_na_colsum(const float* __restrict__ pa
   }
 }
 
+// ---- HGT layer epilogue (round 3):  z = dropout_p( relu?( x + sigmoid(s) * (o - x) ) )  ------------------------------------------
+// PyG HGTConv's learnable skip connection (`out = alpha * out_lin(gelu(agg)) + (1 - alpha) * x`, alpha = sigmoid(skip[type]))
+// followed by the ReLU + dropout the encoders put between layers (via graphmuse HybridHGT, models/analysis.py:445-453): as torch
+// ops that is sigmoid, lerp, relu, dropout forward (4 - 5 launches) and ~7 backward (incl. a full reduction for d skip) per node
+// type and layer — ~90 launches per C3 step, most of them on the beat / measure types' few thousand rows.  Here one launch each
+// way: a wave per row, masks recomputed in backward (ReLU from the recomputed pre-activation, dropout from the counter-based
+// generator), d skip = sigmoid'(s) * sum g (o - x) through per-block partial sums that the LAST block to finish (integer ticket)
+// adds in index order — deterministic, no float atomics.
+struct MixArgs {
+  const float* x;          // skip input [n, H] or NULL (no skip connection: z = act(o))
+  int64_t ld_x;
+  const float* o;
+  int64_t ld_o;
+  const float* skip;       // device scalar s (NULL with x == NULL)
+  int64_t n;
+  int32_t H;
+  float p;
+  uint32_t flags;          // bit 0: ReLU
+  const int64_t* rng;
+  uint32_t call_id;
+};
+
+__device__ __forceinline__ float mix_alpha(const MixArgs& a) { return a.x != nullptr ? 1.f / (1.f + __expf(-*a.skip)) : 1.f; }
+
+template <int CH>
+__global__ __launch_bounds__(256) void k_mix_fwd(MixArgs a, float* __restrict__ z, int64_t ld_z, int64_t* __restrict__ rng_used) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (rng_used != nullptr && a.rng != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    rng_used[0] = a.rng[0];
+    rng_used[1] = a.rng[1];
+  }
+  if (row >= a.n) return;
+  const float al = mix_alpha(a);
+  const bool relu = a.flags & 1u, drop = a.p > 0.f;
+  const float scale = drop ? 1.f / (1.f - a.p) : 1.f;
+  const float4* op = reinterpret_cast<const float4*>(a.o + row * a.ld_o);
+  const float4* xp = a.x != nullptr ? reinterpret_cast<const float4*>(a.x + row * a.ld_x) : nullptr;
+  float4* zp = reinterpret_cast<float4*>(z + row * ld_z);
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    if ((c * 256 + lane * 4) >= a.H) continue;
+    float4 y = op[c * 64 + lane];
+    if (xp != nullptr) {
+      const float4 xv = xp[c * 64 + lane];
+      y = make_float4(fmaf(al, y.x - xv.x, xv.x), fmaf(al, y.y - xv.y, xv.y), fmaf(al, y.z - xv.z, xv.z), fmaf(al, y.w - xv.w, xv.w));
+    }
+    if (relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+    if (drop) {
+      const float4 m = keep_mask(a, row, c * 64 + lane, scale);
+      y.x *= m.x; y.y *= m.y; y.z *= m.z; y.w *= m.w;
+    }
+    zp[c * 64 + lane] = y;
+  }
+}
+
+constexpr int kMixBlocks = 1024;     // partial sums of d skip: one per block
+
+template <int CH>
+__global__ __launch_bounds__(256) void k_mix_bwd(MixArgs a, const float* __restrict__ dz, int64_t ld_dz, float* __restrict__ dx,
+                                                 int64_t ld_dx, float* __restrict__ dout, int64_t ld_do, float* __restrict__ part,
+                                                 unsigned int* __restrict__ ticket, float* __restrict__ dskip) {
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n_waves = gridDim.x * 4;
+  const float al = mix_alpha(a);
+  const bool relu = a.flags & 1u, drop = a.p > 0.f;
+  const float scale = drop ? 1.f / (1.f - a.p) : 1.f;
+  float acc = 0.f;
+  for (int64_t row = wave_g; row < a.n; row += n_waves) {
+    const float4* op = reinterpret_cast<const float4*>(a.o + row * a.ld_o);
+    const float4* xp = a.x != nullptr ? reinterpret_cast<const float4*>(a.x + row * a.ld_x) : nullptr;
+    const float4* gp = reinterpret_cast<const float4*>(dz + row * ld_dz);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if ((c * 256 + lane * 4) >= a.H) continue;
+      const float4 ov = op[c * 64 + lane];
+      const float4 xv = xp != nullptr ? xp[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 g = gp[c * 64 + lane];
+      const float4 d = make_float4(ov.x - xv.x, ov.y - xv.y, ov.z - xv.z, ov.w - xv.w);
+      if (drop) {
+        const float4 m = keep_mask(a, row, c * 64 + lane, scale);
+        g.x *= m.x; g.y *= m.y; g.z *= m.z; g.w *= m.w;
+      }
+      if (relu) {                          // the pre-activation, recomputed exactly as the forward computed it
+        if ((xp != nullptr ? fmaf(al, d.x, xv.x) : ov.x) <= 0.f) g.x = 0.f;
+        if ((xp != nullptr ? fmaf(al, d.y, xv.y) : ov.y) <= 0.f) g.y = 0.f;
+        if ((xp != nullptr ? fmaf(al, d.z, xv.z) : ov.z) <= 0.f) g.z = 0.f;
+        if ((xp != nullptr ? fmaf(al, d.w, xv.w) : ov.w) <= 0.f) g.w = 0.f;
+      }
+      reinterpret_cast<float4*>(dout + row * ld_do)[c * 64 + lane] = make_float4(al * g.x, al * g.y, al * g.z, al * g.w);
+      if (dx != nullptr) {
+        const float be = 1.f - al;
+        reinterpret_cast<float4*>(dx + row * ld_dx)[c * 64 + lane] = make_float4(be * g.x, be * g.y, be * g.z, be * g.w);
+      }
+      acc += (g.x * d.x + g.y * d.y) + (g.z * d.z + g.w * d.w);
+    }
+  }
+  if (dskip == nullptr) return;            // block-uniform
+  acc = wsum(acc);
+  __shared__ float sw[4];
+  __shared__ bool last;
+  if (lane == 0) sw[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float v = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+    const unsigned int before = atomicExch(reinterpret_cast<unsigned int*>(part) + blockIdx.x, __float_as_uint(v));   // device-scope publication
+    asm volatile("" ::"v"(before));
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (last) {
+    __shared__ float sp[kMixBlocks];
+    for (int i = threadIdx.x; i < static_cast<int>(gridDim.x); i += 256) sp[i] = __uint_as_float(atomicOr(reinterpret_cast<unsigned int*>(part) + i, 0u));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int i = 0; i < static_cast<int>(gridDim.x); ++i) t += sp[i];                    // index order: the same bits every run
+      *dskip = t * al * (1.f - al);
+      atomicExch(ticket, 0u);
+    }
+  }
+}
+
 constexpr int kBwdBlocks = 1024;    // 4 waves per SIMD; partial slab = 1024 * 2H floats (one row per block)
 
 int na_check(const char* who, const void* x, int64_t ld_x, const void* gamma, const void* beta, int64_t n, int32_t H, int32_t seg,
@@ -368,4 +493,57 @@ extern "C" int agnn_norm_act_colsum_f32(const void* workspace, size_t workspace_
   hipLaunchKernelGGL(k_na_colsum, dim3((width + 31) / 32), dim3(1024), 0, static_cast<hipStream_t>(stream_),
                      static_cast<const float*>(workspace), nb, width, dgamma, dbeta, H);
   return check_launch("norm_act_colsum");
+}
+
+// ---- HGT layer epilogue -----------------------------------------------------------------------------------------------------
+namespace {
+int mix_check(const char* who, const float* x, int64_t ld_x, const float* o, int64_t ld_o, const float* skip, int64_t n, int32_t H, float p,
+              const void* rng) {
+  using namespace agnn;
+  if (n < 0 || H <= 0 || (H & 3) || H > 2048) return fail(AGNN_EINVAL, "%s: H=%d must be a multiple of 4 in [4,2048], n=%lld", who, H, (long long)n);
+  if (p < 0.f || p >= 1.f) return fail(AGNN_EINVAL, "%s: dropout p=%f", who, p);
+  if (n == 0) return 1;
+  if (!o || (x != nullptr) != (skip != nullptr)) return fail(AGNN_EINVAL, "%s: null output operand, or x and skip not given together", who);
+  if (p > 0.f && !rng) return fail(AGNN_EINVAL, "%s: dropout needs the device rng state", who);
+  if (!aligned16(o) || (ld_o & 3) || ld_o < H || (x && (!aligned16(x) || (ld_x & 3) || ld_x < H))) return fail(AGNN_EALIGN, "%s: misaligned", who);
+  return 0;
+}
+}  // namespace
+
+extern "C" size_t agnn_skip_act_workspace_bytes(void) { return 256 + kMixBlocks * sizeof(float); }
+
+extern "C" int agnn_skip_act_fwd_f32(const float* x, int64_t ld_x, const float* o, int64_t ld_o, const float* skip, int64_t n, int32_t H,
+                                     float p, uint32_t flags, const int64_t* rng_state, uint32_t call_id, float* z, int64_t ld_z,
+                                     int64_t* rng_used, agnn_stream_t stream_) {
+  using namespace agnn;
+  if (int rc = mix_check("skip_act_fwd", x, ld_x, o, ld_o, skip, n, H, p, rng_state)) return rc > 0 ? AGNN_OK : rc;
+  if (!z || !aligned16(z) || (ld_z & 3) || ld_z < H) return fail(AGNN_EALIGN, "skip_act_fwd: output misaligned");
+  MixArgs a{x, ld_x, o, ld_o, skip, n, H, p, flags, rng_state, call_id};
+  const dim3 grid(static_cast<unsigned>((n + 3) / 4)), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  AGNN_NA_DISPATCH(k_mix_fwd, a, z, ld_z, rng_used);
+  return check_launch("skip_act_fwd");
+}
+
+/* workspace: agnn_skip_act_workspace_bytes(), 256-byte aligned, ZERO-FILLED once by the caller; every call leaves its ticket at zero. */
+extern "C" int agnn_skip_act_bwd_f32(const float* x, int64_t ld_x, const float* o, int64_t ld_o, const float* skip, int64_t n, int32_t H,
+                                     float p, uint32_t flags, const int64_t* rng_state, uint32_t call_id, const float* dz, int64_t ld_dz,
+                                     float* dx, int64_t ld_dx, float* dout, int64_t ld_do, float* dskip, void* workspace,
+                                     size_t workspace_bytes, agnn_stream_t stream_) {
+  using namespace agnn;
+  if (int rc = mix_check("skip_act_bwd", x, ld_x, o, ld_o, skip, n, H, p, rng_state)) return rc > 0 ? AGNN_OK : rc;
+  if (!dz || !dout || !aligned16(dz) || !aligned16(dout) || (ld_dz & 3) || (ld_do & 3) || ld_dz < H || ld_do < H) return fail(AGNN_EALIGN, "skip_act_bwd: gradients misaligned");
+  if (dx && (!aligned16(dx) || (ld_dx & 3) || ld_dx < H)) return fail(AGNN_EALIGN, "skip_act_bwd: dx misaligned");
+  if (dskip && (!workspace || workspace_bytes < agnn_skip_act_workspace_bytes() || (reinterpret_cast<uintptr_t>(workspace) & 255u)))
+    return fail(AGNN_ENOMEM, "skip_act_bwd: d skip needs the zero-filled 256-byte aligned workspace");
+  if (dskip && !x) return fail(AGNN_EINVAL, "skip_act_bwd: d skip without a skip connection");
+  MixArgs a{x, ld_x, o, ld_o, skip, n, H, p, flags, rng_state, call_id};
+  int64_t nb = (n + 3) / 4;
+  if (nb > kMixBlocks) nb = kMixBlocks;
+  const dim3 grid(static_cast<unsigned>(nb)), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  unsigned int* ticket = static_cast<unsigned int*>(workspace);
+  float* part = workspace ? reinterpret_cast<float*>(static_cast<char*>(workspace) + 256) : nullptr;
+  AGNN_NA_DISPATCH(k_mix_bwd, a, dz, ld_dz, dx, ld_dx, dout, ld_do, part, ticket, dskip);
+  return check_launch("skip_act_bwd");
 }

@@ -255,7 +255,7 @@ class FlatAdamW:
         self.flat.addcdiv_(self.m / bc1, denom, value=-self.lr)
 
 
-def enable_wgrad_overlap(flag: bool = True, scope: str = "all") -> None:
+def enable_wgrad_overlap(flag: bool = True, scope="all") -> None:
     """Issue weight-gradient GEMMs on their own HIP stream (joined in FlatGradBuffer.pack).  Requires gradients to be
     None when backward starts — FlatGradBuffer(views=False).zero() — see linear.py."""
     from . import linear

@@ -33,7 +33,7 @@ class _SmallEmbedding(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         V = ctx.rows
         Vp = V + (V & 1)                                                   # even width for the kernel
-        with wgrad_stream(dy.device, dy, idx, active=ctx.leaf and all_steal((ctx.weight_ref,))):   # optimizer-only output (linear.py)
+        with wgrad_stream(dy.device, dy, idx, active=ctx.leaf and all_steal((ctx.weight_ref,)), kind="embed"):   # optimizer-only output (linear.py)
             flat_idx = idx.reshape(-1)
             onehot = (flat_idx.unsqueeze(1) == torch.arange(Vp, device=idx.device)).to(dy.dtype)   # [N, Vp]
             dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
@@ -89,7 +89,7 @@ class _EmbedCat(torch.autograd.Function):
         dev = dout.device
         if dout.stride(1) != 1 or dout.dtype != torch.float32:
             dout = dout.float().contiguous()
-        with wgrad_stream(dev, dout, *idc, active=leaf and all_steal(ctx.tab_refs)):   # optimizer-only outputs (linear.py)
+        with wgrad_stream(dev, dout, *idc, active=leaf and all_steal(ctx.tab_refs), kind="embed"):   # optimizer-only outputs (linear.py)
             vocab = (C.c_int32 * n_tab)(*vocabs)
             dtab = torch.empty((sum(vocabs), dim), dtype=torch.float32, device=dev)
             nws = int(lib.agnn_embed_workspace_bytes(n_tab, vocab, dim))

@@ -93,6 +93,83 @@ class _NormAct(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, None, None, None
 
 
+_MIX_WS: Dict[str, torch.Tensor] = {}
+
+
+def _ok16(t: torch.Tensor) -> bool:
+    return t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+
+
+class _SkipAct(torch.autograd.Function):
+    """z = dropout_p(relu?(x + sigmoid(skip) * (o - x)))  (agnn_skip_act_*): the HGT layer's epilogue in one launch each way."""
+
+    @staticmethod
+    def forward(ctx, o, x, skip, relu: bool, p: float, call_id: int):
+        dev = _lib.require_gpu(o)
+        lib = _lib.load()
+        o = o if _ok16(o) else o.float().contiguous()
+        if x is not None:
+            x = x if _ok16(x) else x.float().contiguous()
+        n, H = o.shape
+        z = torch.empty((n, H), dtype=torch.float32, device=dev)
+        rng = rng_state(dev) if p > 0 else None
+        used = torch.empty(2, dtype=torch.int64, device=dev) if p > 0 else None
+        sk = skip.detach().reshape(-1)[:1].contiguous() if skip is not None else None
+        flags = 1 if relu else 0
+        _lib.check(lib.agnn_skip_act_fwd_f32(_lib.ptr(x), x.stride(0) if x is not None else 0, o.data_ptr(), o.stride(0), _lib.ptr(sk), n, H,
+                                             float(p), flags, _lib.ptr(rng), int(call_id), z.data_ptr(), z.stride(0), _lib.ptr(used),
+                                             _lib.stream_ptr(dev)), "agnn_skip_act_fwd_f32")
+        ctx.save_for_backward(o, *([x, sk] if x is not None else []), *([used] if used is not None else []))
+        ctx.cfg = (bool(relu), float(p), int(call_id), x is not None, tuple(skip.shape) if skip is not None else None)
+        ctx.set_materialize_grads(False)          # an undefined output gradient (a structurally dead node type) stays undefined upstream
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        if dz is None:
+            return None, None, None, None, None, None
+        relu, p, call_id, has_x, skip_shape = ctx.cfg
+        saved = list(ctx.saved_tensors)
+        o = saved.pop(0)
+        x, sk = (saved.pop(0), saved.pop(0)) if has_x else (None, None)
+        used = saved.pop(0) if p > 0 else None
+        dev = dz.device
+        lib = _lib.load()
+        dz = dz if _ok16(dz) else dz.float().contiguous()
+        n, H = o.shape
+        do = torch.empty_like(o)
+        want_dx = has_x and ctx.needs_input_grad[1]
+        want_ds = has_x and ctx.needs_input_grad[2]
+        dx = torch.empty((n, H), dtype=torch.float32, device=dev) if want_dx else None
+        ds = torch.empty(1, dtype=torch.float32, device=dev) if want_ds else None
+        ws = None
+        if want_ds:
+            ws = _MIX_WS.get(str(dev))                    # one per device, zero-filled once; every call leaves its ticket at zero
+            if ws is None:
+                ws = _MIX_WS[str(dev)] = torch.zeros(int(lib.agnn_skip_act_workspace_bytes()) + 256, dtype=torch.uint8, device=dev)
+        wsp = ((ws.data_ptr() + 255) & ~255) if ws is not None else None
+        _lib.check(lib.agnn_skip_act_bwd_f32(_lib.ptr(x), x.stride(0) if has_x else 0, o.data_ptr(), o.stride(0), _lib.ptr(sk), n, H, p,
+                                             1 if relu else 0, _lib.ptr(used), call_id, dz.data_ptr(), dz.stride(0), _lib.ptr(dx),
+                                             dx.stride(0) if dx is not None else 0, do.data_ptr(), do.stride(0), _lib.ptr(ds), wsp,
+                                             int(lib.agnn_skip_act_workspace_bytes()) if ws is not None else 0, _lib.stream_ptr(dev)),
+                   "agnn_skip_act_bwd_f32")
+        return do, dx, (ds.reshape(skip_shape) if ds is not None else None), None, None, None
+
+
+def skip_act(o: torch.Tensor, x: Optional[torch.Tensor], skip: Optional[torch.Tensor], relu: bool, p: float, training: bool) -> torch.Tensor:
+    """dropout_p(relu?(lerp(x, o, sigmoid(skip))))  — `x` / `skip` None: no skip connection.  H % 4 == 0 rows on the kernel, anything
+    else on torch ops."""
+    p = float(p) if training else 0.0
+    if not (ENABLED and o.is_cuda and o.dim() == 2 and o.shape[1] % 4 == 0 and o.shape[1] <= 2048 and o.shape[0] > 0 and
+            (x is None or tuple(x.shape) == tuple(o.shape))):
+        y = o if x is None else torch.lerp(x, o, torch.sigmoid(skip))
+        y = F.relu(y) if relu else y
+        return F.dropout(y, p, True) if p > 0 else y
+    if x is None and not relu and p == 0.0:
+        return o
+    return _SkipAct.apply(o, x, skip if x is not None else None, relu, p, next(_CALL_IDS) & 0xFFFFFFFF)
+
+
 def norm_act(x: torch.Tensor, ln: nn.LayerNorm, pre_relu: bool = False, post_relu: bool = False, p: float = 0.0,
              training: bool = False) -> torch.Tensor:
     """dropout_p( relu?( LayerNorm( relu?(x) ) ) ) on the last dimension of x (2-D or 3-D, fp32, H % 4 == 0)."""

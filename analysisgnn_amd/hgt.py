@@ -16,6 +16,7 @@ import torch.nn.functional as F
 from . import _lib
 from .encoders import TrimPlan, _HybridMixin
 from .graph import Csr, HeteroIndex, hetero_index
+from .fused import skip_act
 from .linear import linear
 from .params import cat_rows, pack
 
@@ -550,7 +551,9 @@ class HGTConv(nn.Module):
         self.p_rel = nn.ParameterDict({"__".join(e): nn.Parameter(torch.ones(1, heads)) for e in self.edge_types})
 
     def forward(self, x_dict, edge_index_dict, index: Optional[HeteroIndex] = None,
-                n_keep: Optional[Dict[str, int]] = None, e_keep: Optional[Dict[EdgeType, Optional[int]]] = None):
+                n_keep: Optional[Dict[str, int]] = None, e_keep: Optional[Dict[EdgeType, Optional[int]]] = None, post=None):
+        """`post` = (relu, dropout p, training) or None: the activation the caller would apply to every output right after this
+        layer (HeteroHGTStack between layers) — folded into the layer's epilogue launch; None: the plain HGTConv output."""
         _lib.require_gpu(*x_dict.values())
         if index is None:
             index = hetero_index(edge_index_dict, {k: int(v.shape[0]) for k, v in x_dict.items()})
@@ -558,7 +561,7 @@ class HGTConv(nn.Module):
         D = H // heads
         n_of = {t: (n_keep[t] if n_keep is not None else int(x.shape[0])) for t, x in x_dict.items()}
         if CORE_ENABLED and RELT_ENABLED and D == RELT_D and all(x.shape[1] == self.in_channels for x in x_dict.values()):
-            return self._forward_core(x_dict, index, n_of, e_keep)
+            return self._forward_core(x_dict, index, n_of, e_keep, post)
         # k | q | v in ONE projection per node type; the three H-wide column blocks are handed out as views (col_split)
         k, q, v = {}, {}, {}
         for t, x in x_dict.items():
@@ -609,10 +612,9 @@ class HGTConv(nn.Module):
             else:
                 m = x.new_zeros((n, H))
             o = self.out_lin.lins[t](F.gelu(m))
-            if o.shape[-1] == x.shape[-1]:
-                beta = torch.sigmoid(self.skip[t])
-                o = torch.lerp(x if n >= x.shape[0] else x[:n], o, beta)          # beta * o + (1 - beta) * x in one launch
-            out[t] = o
+            relu, p, training = post if post is not None else (False, 0.0, False)
+            xs = (x if n >= x.shape[0] else x[:n]) if o.shape[-1] == x.shape[-1] else None
+            out[t] = skip_act(o, xs, self.skip[t] if xs is not None else None, relu, p, training)
         return out
 
 
@@ -621,7 +623,7 @@ class HGTConv(nn.Module):
         (dp.plan_parameters) the stack is a view."""
         return [[self.p_rel["__".join(e)] for e in self.edge_types]]
 
-    def _forward_core(self, x_dict, index: HeteroIndex, n_of, e_keep):
+    def _forward_core(self, x_dict, index: HeteroIndex, n_of, e_keep, post=None):
         """One K|Q|V GEMM per node type -> `_HGTCore` (one autograd node for the whole message passing) -> one output GEMM
         per node type (+ skip)."""
         heads, H = self.heads, self.out_channels
@@ -648,9 +650,10 @@ class HGTConv(nn.Module):
             x, n = x_dict[t], n_of[t]
             lo = self.out_lin.lins[t]
             o = linear(F.gelu(m), lo.weight, lo.bias)
-            if o.shape[-1] == x.shape[-1]:
-                o = torch.lerp(x if n >= x.shape[0] else x[:n], o, torch.sigmoid(self.skip[t]))
-            out[t] = o
+            # skip connection (+ the ReLU / dropout the stack puts between layers, when it hands them in): one launch each way
+            relu, p, training = post if post is not None else (False, 0.0, False)
+            xs = (x if n >= x.shape[0] else x[:n]) if o.shape[-1] == x.shape[-1] else None
+            out[t] = skip_act(o, xs, self.skip[t] if xs is not None else None, relu, p, training)
         return out
 
 
@@ -666,9 +669,8 @@ class HeteroHGTStack(nn.Module):
         index.prepare_trim(plan.e_keep)
         self.last_index = index
         for i, conv in enumerate(self.convs):
-            x_dict = conv(x_dict, edge_index_dict, index, plan.n_keep[i], plan.e_keep[i])
-            if i < self.num_layers - 1:
-                x_dict = {k: F.dropout(F.relu(v), self.dropout, self.training) for k, v in x_dict.items()}
+            post = (True, self.dropout, self.training) if i < self.num_layers - 1 else None
+            x_dict = conv(x_dict, edge_index_dict, index, plan.n_keep[i], plan.e_keep[i], post)
             if collect is not None:
                 collect.append(x_dict["note"])
         return x_dict

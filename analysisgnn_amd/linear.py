@@ -29,10 +29,12 @@ ENABLED = True           # A/B switch for benchmarking
 _WG = {"enabled": False, "scope": "all", "streams": {}, "dirty": set()}
 
 
-def enable_wgrad_overlap(flag: bool = True, scope: str = "all") -> None:
-    """scope "all": every projection; "sequence": only the GRU layers' weight-gradient work (the recurrence chain)."""
+def enable_wgrad_overlap(flag: bool = True, scope="all") -> None:
+    """scope "all": every projection; otherwise the kinds of work that go to the weight-gradient stream, one name or several
+    ("sequence": the GRU layers' weight gradients — the recurrence chain; "embed": the embedding tables' gradient, the last node
+    of the backward pass, which then runs beside the input layers' deferred weight gradients instead of in front of them)."""
     _WG["enabled"] = bool(flag)
-    _WG["scope"] = scope
+    _WG["scope"] = scope if scope == "all" else frozenset([scope] if isinstance(scope, str) else scope)
 
 
 def wgrad_overlap_enabled() -> bool:
@@ -104,7 +106,7 @@ class wgrad_stream:
     the current stream) and keeps `inputs` alive for it; a no-op context when the overlap is disabled."""
 
     def __init__(self, dev, *inputs, active: bool = True, kind: str = "linear"):
-        self.on = bool(_WG["enabled"] and active and torch.device(dev).type == "cuda" and (_WG["scope"] == "all" or kind == _WG["scope"]))
+        self.on = bool(_WG["enabled"] and active and torch.device(dev).type == "cuda" and (_WG["scope"] == "all" or kind in _WG["scope"]))
         self.dev, self.inputs = torch.device(dev), inputs
 
     def __enter__(self):

@@ -78,6 +78,7 @@ def parse_args(argv=None):
                     help="backward schedule of the hybrid encoders: capture both and keep the faster (auto), or force one")
     ap.add_argument("--no-defer", action="store_true", help="A/B only: weight gradients where they are computed, not deferred")
     ap.add_argument("--no-wgrad-overlap", action="store_true", help="A/B only: weight gradients on the main stream")
+    ap.add_argument("--wgrad-scope", default="sequence", help="A/B only: kinds of weight-gradient work on the side stream")
     ap.add_argument("--library-wgrad", action="store_true", help="A/B only: weight gradients through the library GEMM")
     ap.add_argument("--blas", default=None, choices=[None, "hipblaslt", "rocblas"], help="A/B only: torch's preferred BLAS library")
     ap.add_argument("--graph-dot", default=None, help="debugging: write the captured step's dependency graph as DOT to this path")
@@ -332,7 +333,9 @@ def main():
     flat = dp.FlatGradBuffer(params, views=False, tight=tight, late=late)
     # the GRU layers' weight-gradient work on its own stream, joined in flat.pack() — only where the sequence branch is
     # the longer one (C2; with HGT / MetricalGNN the graph branch is, and the extra stream only adds contention)
-    dp.enable_wgrad_overlap(not args.no_wgrad_overlap and args.workload in ("c2", "c2s"), "sequence")
+    # (round 3, measured and not kept: + "embed" — the embedding tables' gradient, the backward pass's last node, beside the input
+    # layers' deferred weight gradients: 3.376 vs 3.346 ms, two alternating pairs on one box; `--wgrad-scope sequence,embed`)
+    dp.enable_wgrad_overlap(not args.no_wgrad_overlap and args.workload in ("c2", "c2s"), args.wgrad_scope.split(","))
     # dW / db of the projections on the main stream wait until that stream has slack (the GNN stack's backward is done, the
     # sequence branch's is not): the hybrid encoders only
     dp.defer_weight_grads(not args.no_defer and enc in ("hybridgnn", "hgt"))

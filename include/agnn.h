@@ -327,6 +327,20 @@ int agnn_norm_act_bwd_f32(const float* x, int64_t ld_x, const float* gamma, cons
 /* agnn_norm_act_bwd_f32 with dgamma == dbeta == NULL leaves the per-block partial sums in `workspace` and launches only the
  * input-gradient kernel; this entry point turns them into dgamma / dbeta later (same n, H, workspace): the two parameter
  * gradients only feed the optimizer and need not sit on the backward pass's dependent chain. */
+/* HGT layer epilogue in one launch each way (round 3):  z = dropout_p( relu?( x + sigmoid(*skip) * (o - x) ) )  — PyG HGTConv's
+ * learnable skip connection (alpha = sigmoid(skip[node type])) followed by the ReLU + dropout the encoders put between layers
+ * (graphmuse HybridHGT via models/analysis.py:445-453).  x == skip == NULL: no skip connection, z = act(o).  flags bit 0 = ReLU.
+ * Dropout as agnn_norm_act_* (counter-based masks; `rng_used` receives the (seed, step) this call drew from, backward takes it).
+ * Backward recomputes both masks, writes d o (= alpha g), d x (= (1 - alpha) g, optional) and d skip (optional; needs
+ * `workspace`: agnn_skip_act_workspace_bytes(), 256-byte aligned, ZERO-FILLED once by the caller — every call leaves it so). */
+size_t agnn_skip_act_workspace_bytes(void);
+int agnn_skip_act_fwd_f32(const float* x, int64_t ld_x, const float* o, int64_t ld_o, const float* skip, int64_t n, int32_t H, float p,
+                          uint32_t flags, const int64_t* rng_state, uint32_t call_id, float* z, int64_t ld_z, int64_t* rng_used,
+                          agnn_stream_t stream);
+int agnn_skip_act_bwd_f32(const float* x, int64_t ld_x, const float* o, int64_t ld_o, const float* skip, int64_t n, int32_t H, float p,
+                          uint32_t flags, const int64_t* rng_state, uint32_t call_id, const float* dz, int64_t ld_dz, float* dx,
+                          int64_t ld_dx, float* dout, int64_t ld_do, float* dskip, void* workspace, size_t workspace_bytes,
+                          agnn_stream_t stream);
 int agnn_norm_act_colsum_f32(const void* workspace, size_t workspace_bytes, int64_t n, int32_t H, float* dgamma, float* dbeta,
                              agnn_stream_t stream);
 

@@ -200,3 +200,42 @@ def test_relation_transform_kernels_match_float64(N, R, heads, T):
     assert_close(kd.grad, kqv64.grad.float(), 1e-5, "d kqv")
     assert_close(wkd.grad, wk64.grad.float(), 1e-5, "d k_rel.weight")
     assert_close(wvd.grad, wv64.grad.float(), 1e-5, "d v_rel.weight")
+
+
+@pytest.mark.parametrize("n,H,relu,p,with_x", [(16000, 256, True, 0.0, True), (3584, 256, True, 0.3, True), (897, 64, False, 0.0, True),
+                                                (50, 256, True, 0.0, False)])
+def test_skip_act_epilogue_matches_torch(n, H, relu, p, with_x):
+    """agnn_skip_act_*: z = dropout(relu(lerp(x, o, sigmoid(skip)))) in one launch each way against the torch ops it replaces
+    (float64): values, d o, d x and the scalar d skip (a deterministic ticket reduction).  With dropout the mask is the library's
+    own: checked through its invariants (kept elements = value / (1 - p), dropped = 0, rate ~ p) and by replaying the backward
+    through the SAME mask (read off the forward result)."""
+    from analysisgnn_amd.fused import skip_act
+    from helpers import assert_close_rel
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(n + H)
+    o = torch.randn(n, H, generator=g)
+    x = torch.randn(n, H, generator=g) if with_x else None
+    skip = torch.tensor([0.3]) if with_x else None
+    od = o.to(dev).requires_grad_(True)
+    xd = x.to(dev).requires_grad_(True) if with_x else None
+    sd = skip.to(dev).requires_grad_(True) if with_x else None
+    z = skip_act(od, xd, sd, relu, p, True)
+    gz = torch.randn(n, H, generator=g)
+    z.backward(gz.to(dev))
+    o64 = o.double().requires_grad_(True)
+    x64 = x.double().requires_grad_(True) if with_x else None
+    s64 = skip.double().requires_grad_(True) if with_x else None
+    y = o64 if not with_x else torch.lerp(x64, o64, torch.sigmoid(s64))
+    y = torch.relu(y) if relu else y
+    if p > 0:
+        zc = z.detach().cpu().double()
+        keep = (zc != 0) | (y.detach() == 0)                       # where the forward kept the element (exact zeros of y: either way)
+        rate = 1.0 - float(((zc != 0).sum()) / max(int((y.detach() != 0).sum()), 1))
+        assert abs(rate - p) < 0.02, rate
+        y = y * keep.double() / (1.0 - p)
+    assert_close_rel(z, y.detach(), 1e-6, "z")
+    y.backward(gz.double())
+    assert_close_rel(od.grad, o64.grad, 1e-6, "d o")
+    if with_x:
+        assert_close_rel(xd.grad, x64.grad, 1e-6, "d x")
+        assert_close_rel(sd.grad, s64.grad, 1e-5, "d skip")
