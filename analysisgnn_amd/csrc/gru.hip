@@ -14,7 +14,8 @@
 
 namespace {
 
-constexpr int HH = 128;        // hidden size per direction
+// hidden size per direction: template parameter HH of the kernels, 128 (H = 256 models: the C2 / C3 configurations) or 64
+// (H = 128).  256 (H = 512) does not fit: W_hh = 768 x 256 fp32 = 768 KB against 512 KB of registers + 160 KB of LDS per CU.
 constexpr int NT = 512;        // threads per chain: 8 waves = 8 chunks of the reduction dimension
 constexpr int KC = 8;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -47,30 +48,33 @@ __device__ __forceinline__ float tanhf_(float x) { return 2.f * __builtin_amdgcn
 // unconditional loads / stores and counted s_waitcnt (a branch around a memory operation makes the compiler wait for
 // ALL outstanding operations at the join, which put one memory round trip into every step).
 // Tried, slower: two EXTRA waves for phase 2 (640 threads) with their stores deferred behind the second barrier.
-constexpr int PSTR = 3 * HH;           // part[kc][gate*HH + unit]
 
 // Inter-layer dropout rides along (nn.GRU(dropout=p), models/cadence.py:249-251): `drop` [B, T, 2*HH] holds 0 or 1 / (1 - p)
 // per element and `y2` receives y * drop — what the next layer reads — while `y` stays the layer's own state; without
 // dropout the host passes drop = any readable matrix of that size, use = 0 and y2 = y (the loads / stores stay
 // unconditional: a branch around a memory operation costs a full wait in this loop).  One launch less on the recurrence
 // chain in each direction (the backward kernel applies the same factor to dy).
+template <int HH>
 __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, const float* __restrict__ w_hh,
                                                  const float* __restrict__ b_hh, int T, float* __restrict__ y,
                                                  float* __restrict__ saved, const float* __restrict__ drop, float use,
                                                  float* __restrict__ y2) {
+  constexpr int PSTR = 3 * HH;           // part[kc][gate*HH + unit]
+  constexpr int RPL = 3 * HH / 64;       // rows of W_hh per lane (6 at HH = 128, 3 at 64)
+  constexpr int CPW = HH / KC;           // columns of W_hh per wave (16 / 8)
   __shared__ __attribute__((aligned(16))) float hbuf[2][HH];
   __shared__ __attribute__((aligned(16))) float part[KC * PSTR];
   const int b = blockIdx.x >> 1, d = blockIdx.x & 1;
   const int tid = threadIdx.x, lane = tid & 63;
   const int kc = __builtin_amdgcn_readfirstlane(tid >> 6);       // this WAVE's k chunk: its h values are wave-uniform
   const float* W = w_hh + static_cast<size_t>(d) * 3 * HH * HH;
-  // lane -> the six rows {lane + 64 i} of W_hh (row = gate*HH + unit), columns [16 kc, 16 kc + 16)
-  f32x2 w[6][8];
+  // lane -> the RPL rows {lane + 64 i} of W_hh (row = gate*HH + unit), columns [CPW kc, CPW kc + CPW)
+  f32x2 w[RPL][CPW / 2];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const float4* src = reinterpret_cast<const float4*>(W + static_cast<size_t>(lane + 64 * i) * HH + 16 * kc);
+  for (int i = 0; i < RPL; ++i) {
+    const float4* src = reinterpret_cast<const float4*>(W + static_cast<size_t>(lane + 64 * i) * HH + CPW * kc);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < CPW / 4; ++v) {
       const float4 t4 = src[v];
       w[i][2 * v] = f32x2{t4.x, t4.y};
       w[i][2 * v + 1] = f32x2{t4.z, t4.w};
@@ -80,19 +84,19 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
   __syncthreads();
 
   auto phase1 = [&](int cur) {
-    f32x2 hk[8];
-    const float4* hp = reinterpret_cast<const float4*>(&hbuf[cur][16 * kc]);      // same address in every lane: LDS broadcast
+    f32x2 hk[CPW / 2];
+    const float4* hp = reinterpret_cast<const float4*>(&hbuf[cur][CPW * kc]);     // same address in every lane: LDS broadcast
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < CPW / 4; ++v) {
       const float4 t4 = hp[v];
       hk[2 * v] = f32x2{t4.x, t4.y};
       hk[2 * v + 1] = f32x2{t4.z, t4.w};
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < RPL; ++i) {
       f32x2 a = {0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < 8; ++k) a = __builtin_elementwise_fma(w[i][k], hk[k], a);
+      for (int k = 0; k < CPW / 2; ++k) a = __builtin_elementwise_fma(w[i][k], hk[k], a);
       part[kc * PSTR + lane + 64 * i] = a.x + a.y;             // consecutive lanes, consecutive words: conflict-free
     }
   };
@@ -175,6 +179,7 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
 //            by phase B of the previous step; gate gradients; dgi / dgh to HBM; the three dgh vectors to LDS;
 //   phase B (all 8 waves; wave = 48 rows of W_hh, lane = two hidden units): the wave's 48 dgh values from LDS (one
 //            address for all lanes), 48 packed FMAs, two partial sums to LDS.
+template <int HH>
 __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, const float* __restrict__ y,
                                                  const float* __restrict__ saved, const float* __restrict__ w_hh,
                                                  int T, float* __restrict__ dgi, float* __restrict__ dgh_out,
@@ -185,7 +190,9 @@ __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, co
   const int b = blockIdx.x >> 1, d = blockIdx.x & 1;
   const int tid = threadIdx.x;
   const int kc = __builtin_amdgcn_readfirstlane(tid >> 6);       // this WAVE's chunk of 48 rows j of W_hh: dgh[j] is wave-uniform
-  const int u0 = 2 * (tid & 63);                                 // lane -> hidden units u0, u0 + 1
+  const int u_raw = 2 * (tid & 63);                              // lane -> hidden units u0, u0 + 1
+  const bool u_on = u_raw < HH;                                  // HH = 64: lanes 32..63 carry no units (they repeat a pair, store nothing)
+  const int u0 = u_on ? u_raw : HH - 2;
   const float* W = w_hh + static_cast<size_t>(d) * 3 * HH * HH;
   constexpr int JC = 3 * HH / KC;   // 48 rows of W per wave
   f32x2 wa[JC / 2], wb[JC / 2];     // unit u0 / u0+1: (W[j][u], W[j+1][u]) pairs over the chunk's rows
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, co
       a0 = __builtin_elementwise_fma(wa[2 * v + 1], hi, a0);
       a1 = __builtin_elementwise_fma(wb[2 * v + 1], hi, a1);
     }
-    *reinterpret_cast<float2*>(&cpart[kc * CSTR + u0]) = make_float2(a0.x + a0.y, a1.x + a1.y);
+    if (u_on) *reinterpret_cast<float2*>(&cpart[kc * CSTR + u0]) = make_float2(a0.x + a0.y, a1.x + a1.y);
   };
 
   if (tid >= HH) {                       // waves 2..7: mat-vec only
@@ -283,6 +290,7 @@ __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, co
 
 // h_{t-1} of both directions as one [B*T, 2*HH] matrix — the left operand of the W_hh weight-gradient GEMMs:
 // forward half = y[b, t-1, :HH] (zero at t = 0), reverse half = y[b, t+1, HH:] (zero at t = T-1).  One pass, 16-byte lanes.
+template <int HH>
 __global__ __launch_bounds__(256) void k_gru_hprev(const float* __restrict__ y, int T, int64_t total4, float* __restrict__ hp) {
   constexpr int Q = 2 * HH / 4;          // float4 per row
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < total4; e += static_cast<int64_t>(gridDim.x) * 256) {
@@ -301,7 +309,8 @@ __global__ __launch_bounds__(256) void k_gru_hprev(const float* __restrict__ y, 
 
 extern "C" int agnn_gru_hprev_f32(const float* y, int64_t B, int64_t T, int32_t hidden, float* hp, agnn_stream_t stream_) {
   using namespace agnn;
-  if (hidden != HH) return fail(AGNN_EINVAL, "gru_hprev: hidden=%d unsupported (this build: %d)", hidden, HH);
+  if (hidden != 128 && hidden != 64) return fail(AGNN_EINVAL, "gru_hprev: hidden=%d unsupported (this build: 64, 128)", hidden);
+  const int HH = hidden;
   if (B < 0 || T < 0 || T >= (int64_t{1} << 31)) return fail(AGNN_EINVAL, "gru_hprev: bad B=%lld T=%lld", (long long)B, (long long)T);
   if (B == 0 || T == 0) return AGNN_OK;
   if (!y || !hp) return fail(AGNN_EINVAL, "gru_hprev: null argument");
@@ -309,8 +318,8 @@ extern "C" int agnn_gru_hprev_f32(const float* y, int64_t B, int64_t T, int32_t 
   const int64_t total4 = B * T * (2 * HH / 4);
   int64_t blocks = (total4 + 255) / 256;
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(k_gru_hprev, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream_), y,
-                     static_cast<int>(T), total4, hp);
+  if (hidden == 128) hipLaunchKernelGGL(k_gru_hprev<128>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream_), y, static_cast<int>(T), total4, hp);
+  else hipLaunchKernelGGL(k_gru_hprev<64>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream_), y, static_cast<int>(T), total4, hp);
   return check_launch("gru_hprev");
 }
 
@@ -318,15 +327,18 @@ extern "C" int agnn_gru_fwd_f32(const float* gi, const float* w_hh, const float*
                                 int32_t hidden, float* y, float* saved, const float* drop_scale, float* y_drop,
                                 agnn_stream_t stream_) {
   using namespace agnn;
-  if (hidden != HH) return fail(AGNN_EINVAL, "gru_fwd: hidden=%d unsupported (this build: %d)", hidden, HH);
+  if (hidden != 128 && hidden != 64) return fail(AGNN_EINVAL, "gru_fwd: hidden=%d unsupported (this build: 64, 128)", hidden);
   if (B < 0 || T < 0 || B * 2 >= (int64_t{1} << 31) || T >= (int64_t{1} << 31)) return fail(AGNN_EINVAL, "gru_fwd: bad B=%lld T=%lld", (long long)B, (long long)T);
   if (B == 0 || T == 0) return AGNN_OK;
   if (!gi || !w_hh || !b_hh || !y || !saved) return fail(AGNN_EINVAL, "gru_fwd: null argument");
   if (!aligned16(gi) || !aligned16(w_hh) || !aligned16(y) || !aligned16(saved)) return fail(AGNN_EALIGN, "gru_fwd: pointers must be 16-byte aligned");
   if ((drop_scale == nullptr) != (y_drop == nullptr)) return fail(AGNN_EINVAL, "gru_fwd: drop_scale and y_drop go together");
-  hipLaunchKernelGGL(k_gru_fwd, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), gi,
-                       w_hh, b_hh, static_cast<int>(T), y, saved, drop_scale ? drop_scale : y, drop_scale ? 1.f : 0.f,
-                       y_drop ? y_drop : y);
+  if (hidden == 128)
+    hipLaunchKernelGGL(k_gru_fwd<128>, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), gi, w_hh, b_hh,
+                       static_cast<int>(T), y, saved, drop_scale ? drop_scale : y, drop_scale ? 1.f : 0.f, y_drop ? y_drop : y);
+  else
+    hipLaunchKernelGGL(k_gru_fwd<64>, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), gi, w_hh, b_hh,
+                       static_cast<int>(T), y, saved, drop_scale ? drop_scale : y, drop_scale ? 1.f : 0.f, y_drop ? y_drop : y);
   return check_launch("gru_fwd");
 }
 
@@ -334,12 +346,16 @@ extern "C" int agnn_gru_bwd_f32(const float* dy, const float* y, const float* sa
                                 int64_t T, int32_t hidden, float* dgi, float* dgh, const float* drop_scale,
                                 agnn_stream_t stream_) {
   using namespace agnn;
-  if (hidden != HH) return fail(AGNN_EINVAL, "gru_bwd: hidden=%d unsupported (this build: %d)", hidden, HH);
+  if (hidden != 128 && hidden != 64) return fail(AGNN_EINVAL, "gru_bwd: hidden=%d unsupported (this build: 64, 128)", hidden);
   if (B < 0 || T < 0 || B * 2 >= (int64_t{1} << 31) || T >= (int64_t{1} << 31)) return fail(AGNN_EINVAL, "gru_bwd: bad B=%lld T=%lld", (long long)B, (long long)T);
   if (B == 0 || T == 0) return AGNN_OK;
   if (!dy || !y || !saved || !w_hh || !dgi || !dgh) return fail(AGNN_EINVAL, "gru_bwd: null argument");
   if (!aligned16(dy) || !aligned16(y) || !aligned16(saved) || !aligned16(w_hh) || !aligned16(dgi) || !aligned16(dgh)) return fail(AGNN_EALIGN, "gru_bwd: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL(k_gru_bwd, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), dy, y,
-                       saved, w_hh, static_cast<int>(T), dgi, dgh, drop_scale ? drop_scale : y, drop_scale ? 1.f : 0.f);
+  if (hidden == 128)
+    hipLaunchKernelGGL(k_gru_bwd<128>, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), dy, y, saved, w_hh,
+                       static_cast<int>(T), dgi, dgh, drop_scale ? drop_scale : y, drop_scale ? 1.f : 0.f);
+  else
+    hipLaunchKernelGGL(k_gru_bwd<64>, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), dy, y, saved, w_hh,
+                       static_cast<int>(T), dgi, dgh, drop_scale ? drop_scale : y, drop_scale ? 1.f : 0.f);
   return check_launch("gru_bwd");
 }

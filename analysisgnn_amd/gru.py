@@ -13,7 +13,7 @@ import torch.nn.functional as F
 from . import _lib
 from .linear import all_steal, defer, defer_home, deferring, leaf_refs, mark_wgrad_async, weight_grad, wgrad_stream
 
-KERNEL_HIDDEN = 128
+KERNEL_HIDDEN = (64, 128)      # hidden sizes per direction the kernels are instantiated for (H = 128 / 256 hybrid models)
 
 
 class _GRULayer(torch.autograd.Function):
@@ -105,13 +105,14 @@ class _GRULayer(torch.autograd.Function):
 
 
 def kernel_applicable(rnn: nn.GRU) -> bool:
-    return (isinstance(rnn, nn.GRU) and rnn.hidden_size == KERNEL_HIDDEN and rnn.bidirectional and rnn.batch_first
+    return (isinstance(rnn, nn.GRU) and rnn.hidden_size in KERNEL_HIDDEN and rnn.bidirectional and rnn.batch_first
             and rnn.bias and getattr(rnn, "proj_size", 0) == 0)
 
 
 def gru_forward(rnn: nn.GRU, x: torch.Tensor, training: bool) -> torch.Tensor:
-    """y = rnn(x)[0] with zero initial state.  Persistent HIP kernels when hidden_size == 128
-    (H = 256 models); any other size runs the library RNN (MIOpen) — still on the GPU."""
+    """y = rnn(x)[0] with zero initial state.  Persistent HIP kernels when hidden_size is 64 or 128 (H = 128 / 256 models);
+    any other size runs the library RNN (MIOpen) — still on the GPU (hidden 256 = H 512: W_hh does not fit one CU's registers
+    + LDS)."""
     _lib.require_gpu(x)
     if not kernel_applicable(rnn):
         return rnn(x)[0]

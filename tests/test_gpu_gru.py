@@ -11,11 +11,11 @@ from helpers import assert_close  # noqa: E402
 DEV = "cuda:0"
 
 
-def _run(B, T, I, layers, seed, fast_oracle=False):
+def _run(B, T, I, layers, seed, fast_oracle=False, hidden=128):
     from analysisgnn_amd.gru import gru_forward
     from oracle import rnn_ref
     torch.manual_seed(seed)
-    m = torch.nn.GRU(I, 128, num_layers=layers, batch_first=True, bidirectional=True)
+    m = torch.nn.GRU(I, hidden, num_layers=layers, batch_first=True, bidirectional=True)
     with torch.no_grad():                      # larger recurrent weights: make the chain matter
         for n, p in m.named_parameters():
             if "weight_hh" in n:
@@ -39,6 +39,15 @@ def _run(B, T, I, layers, seed, fast_oracle=False):
 @pytest.mark.parametrize("B,T,I,layers", [(1, 1, 8, 1), (3, 37, 64, 1), (2, 19, 256, 2), (5, 64, 32, 2)])
 def test_gru_small(B, T, I, layers):
     _run(B, T, I, layers, seed=B * 100 + T)
+
+
+@pytest.mark.parametrize("B,T,I,layers", [(1, 1, 8, 1), (3, 37, 64, 1), (4, 50, 128, 2)])
+def test_gru_hidden_64(B, T, I, layers):
+    """The hidden-64 instantiation (HybridGNN / HybridHGT at H = 128): three rows of W_hh per lane, eight columns per wave, the
+    gate math on wave 0 only; backward with half the lanes carrying units."""
+    from analysisgnn_amd.gru import kernel_applicable
+    assert kernel_applicable(torch.nn.GRU(I, 64, num_layers=layers, batch_first=True, bidirectional=True))
+    _run(B, T, I, layers, seed=B * 10 + T, hidden=64)
 
 
 def test_gru_c2_shape():
