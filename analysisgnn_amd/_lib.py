@@ -63,6 +63,12 @@ class Gated(C.Structure):
                 ("H", C.c_int32)]
 
 
+class WgradItem(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("ld_dy", C.c_int64), ("ld_x", C.c_int64),
+                ("ld_dw", C.c_int64), ("n", C.c_int64), ("out_f", C.c_int32), ("in_f", C.c_int32)]
+
+
+WGRAD_BATCH_MAX = 16
 PACK_MAX_SRC = 8
 
 
@@ -116,6 +122,8 @@ SIGNATURES = {
     "agnn_relt_dw_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int64]),
     "agnn_relt_dw_f32": (C.c_int, [C.c_int, C.POINTER(ReltItem), C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_size_t,
                                   C.c_void_p]),
+    "agnn_wgrad_batch_workspace_bytes": (C.c_size_t, [C.c_int32, C.POINTER(WgradItem)]),
+    "agnn_wgrad_batch_f32": (C.c_int, [C.c_int32, C.POINTER(WgradItem), C.c_void_p, C.c_size_t, C.c_void_p]),
     "agnn_gemm_nt_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_int64, C.c_void_p]),
     "agnn_absdiff_fwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,

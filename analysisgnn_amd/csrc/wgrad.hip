@@ -30,11 +30,10 @@ struct WgArgs {
   int32_t out_pad, in_pad;
 };
 
-__global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
+__device__ __forceinline__ void wgrad_tile(const WgArgs& a, const int tile, const int slice) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tile = blockIdx.x, slice = blockIdx.y;
   const int to = tile / a.tiles_in, ti = tile - to * a.tiles_in;
   const int kk = lane >> 5, c32 = lane & 31;
   const int ocol = to * 128 + wm * 64 + 2 * c32;     // this lane's two output-feature columns of dY
@@ -135,18 +134,47 @@ __global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
   }
 }
 
+__global__ __launch_bounds__(256) void k_wgrad(WgArgs a) { wgrad_tile(a, blockIdx.x, blockIdx.y); }
+
+// ---- several weight gradients in ONE launch (round 3) ------------------------------------------------------------------------
+// A training step computes ~20 of these products, most of them small (256 x 256, 384 x 128, 128 x 128 ... outputs): alone, each
+// needs up to 64 row slices to put a workgroup on every CU — 64 slabs written and read back per output, a 250-row K loop per
+// workgroup, and a reduction launch of its own (20 x ~11 us per step).  The deferred weight gradients (dp.defer_weight_grads) are
+// pending TOGETHER at the encoder's flush points, so they are issued together: the workgroups of all items fill the chip, every
+// item gets by with the same few slices (640 / total tiles: 6 at the GNN stack's flush), K loops of thousands of rows, and ONE
+// reduction launch serves all outputs.
+constexpr int kWgBatchMax = 16;
+
+struct WgBatch {
+  WgArgs it[kWgBatchMax];
+  int32_t first[kWgBatchMax + 1];        // first workgroup of item i (prefix sums of tiles_i * S_i)
+  int32_t tiles[kWgBatchMax];
+  int32_t n;
+};
+
+__global__ __launch_bounds__(256) void k_wgrad_batch(WgBatch b) {
+  int i = 0;
+  const int blk = blockIdx.x;
+  while (i + 1 < b.n && blk >= b.first[i + 1]) ++i;              // workgroup-uniform
+  const int local = blk - b.first[i];
+  const int tiles = b.tiles[i];
+  const int slice = local / tiles;
+  wgrad_tile(b.it[i], local - slice * tiles, slice);
+}
+
+
 // dw[o][i] = sum_s slab[s][o][i] ;  db[o] = sum_s slab_b[s][o]   (fixed order: 8 interleaved partial sums, then a
 // fixed tree).  A block = 32 float2 columns x 8 slab groups, so the S slab reads of one output element are
 // spread over 8 threads with independent loads in flight instead of one thread walking S strided lines.
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slab, const float* __restrict__ slab_b, int S,
-                                                      int out_f, int in_f, int out_pad, int in_pad, float* __restrict__ dw,
-                                                      int64_t ld_dw, float* __restrict__ db) {
+__device__ __forceinline__ void wgrad_reduce_blocks(const float* __restrict__ slab, const float* __restrict__ slab_b, int S, int out_f, int in_f,
+                                                    int out_pad, int in_pad, float* __restrict__ dw, int64_t ld_dw, float* __restrict__ db,
+                                                    const int block, const int n_blocks) {
   __shared__ float2 part[8][32];
   const int col = threadIdx.x & 31, sg = threadIdx.x >> 5;
   const int half_in = in_f >> 1;
   const int64_t total = static_cast<int64_t>(out_f) * half_in;
   const int64_t plane = static_cast<int64_t>(out_pad) * in_pad;
-  for (int64_t e0 = static_cast<int64_t>(blockIdx.x) * 32; e0 < total; e0 += static_cast<int64_t>(gridDim.x) * 32) {
+  for (int64_t e0 = static_cast<int64_t>(block) * 32; e0 < total; e0 += static_cast<int64_t>(n_blocks) * 32) {
     const int64_t e = e0 + col;
     float2 s = make_float2(0.f, 0.f);
     int o = 0, i = 0;
@@ -173,7 +201,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
   if (db != nullptr) {
     // same 32 x 8 decomposition for the bias slabs (a serial walk over S slabs cost ~19 us of load latency)
     __shared__ float partb[8][32];
-    for (int e0 = blockIdx.x * 32; e0 < out_f; e0 += gridDim.x * 32) {
+    for (int e0 = block * 32; e0 < out_f; e0 += n_blocks * 32) {
       const int e = e0 + col;
       float s = 0.f;
       if (e < out_f)
@@ -189,6 +217,34 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
       __syncthreads();
     }
   }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slab, const float* __restrict__ slab_b, int S,
+                                                      int out_f, int in_f, int out_pad, int in_pad, float* __restrict__ dw,
+                                                      int64_t ld_dw, float* __restrict__ db) {
+  wgrad_reduce_blocks(slab, slab_b, S, out_f, in_f, out_pad, in_pad, dw, ld_dw, db, blockIdx.x, gridDim.x);
+}
+
+struct RedItem {
+  const float* slab;
+  const float* slab_b;
+  float* dw;
+  float* db;
+  int64_t ld_dw;
+  int32_t S, out_f, in_f, out_pad, in_pad;
+};
+struct RedBatch {
+  RedItem it[kWgBatchMax];
+  int32_t first[kWgBatchMax + 1];
+  int32_t n;
+};
+
+__global__ __launch_bounds__(256) void k_wgrad_reduce_batch(RedBatch b) {
+  int i = 0;
+  const int blk = blockIdx.x;
+  while (i + 1 < b.n && blk >= b.first[i + 1]) ++i;
+  const RedItem& r = b.it[i];
+  wgrad_reduce_blocks(r.slab, r.slab_b, r.S, r.out_f, r.in_f, r.out_pad, r.in_pad, r.dw, r.ld_dw, r.db, blk - b.first[i], b.first[i + 1] - b.first[i]);
 }
 
 struct Plan {
@@ -261,4 +317,98 @@ extern "C" int agnn_wgrad_f32(const float* dy, int64_t ld_dy, const float* x, in
   hipLaunchKernelGGL(k_wgrad, dim3(p.tiles_out * p.tiles_in, p.S), dim3(256), 0, s, a);
   if (int rc = check_launch("wgrad")) return rc;
   return launch_slab_reduce(slab, db ? slab_b : nullptr, p.S, out_f, in_f, p.out_pad, p.in_pad, dw, ld_dw, db, s);
+}
+
+namespace {
+struct BatchPlan {
+  int n;
+  int tiles_out[kWgBatchMax], tiles_in[kWgBatchMax], S[kWgBatchMax], rps[kWgBatchMax];
+  size_t slab_off[kWgBatchMax], slabb_off[kWgBatchMax], total_floats;
+};
+
+// one slice count for the whole batch: ~2.5 workgroups per CU over all items together, K loops of >= 64 rows
+int batch_plan(int n_items, const agnn_wgrad_item_t* items, BatchPlan& bp) {
+  using namespace agnn;
+  if (n_items <= 0 || n_items > kWgBatchMax || !items) return fail(AGNN_EINVAL, "wgrad_batch: %d items (1 .. %d)", n_items, kWgBatchMax);
+  bp.n = n_items;
+  int64_t tiles = 0;
+  for (int i = 0; i < n_items; ++i) {
+    const agnn_wgrad_item_t& it = items[i];
+    if (it.n <= 0 || it.n >= (int64_t{1} << 31) || it.out_f <= 0 || it.in_f <= 0) return fail(AGNN_EINVAL, "wgrad_batch: item %d: bad sizes", i);
+    bp.tiles_out[i] = (it.out_f + 127) / 128;
+    bp.tiles_in[i] = (it.in_f + 127) / 128;
+    tiles += static_cast<int64_t>(bp.tiles_out[i]) * bp.tiles_in[i];
+  }
+  int64_t S = 640 / tiles;
+  if (S > 64) S = 64;
+  if (S < 1) S = 1;
+  size_t off = 0;
+  for (int i = 0; i < n_items; ++i) {
+    const agnn_wgrad_item_t& it = items[i];
+    int64_t s_i = S;
+    const int64_t max_s = (it.n + 63) / 64;
+    if (s_i > max_s) s_i = max_s;
+    int64_t rps = (it.n + s_i - 1) / s_i;
+    rps = (rps + 1) & ~int64_t{1};
+    bp.rps[i] = static_cast<int>(rps);
+    bp.S[i] = static_cast<int>((it.n + rps - 1) / rps);
+    const size_t plane = static_cast<size_t>(bp.tiles_out[i]) * 128 * bp.tiles_in[i] * 128;
+    bp.slab_off[i] = off;
+    off += static_cast<size_t>(bp.S[i]) * plane;
+    bp.slabb_off[i] = off;
+    off += static_cast<size_t>(bp.S[i]) * bp.tiles_out[i] * 128;
+    off = (off + 63) & ~size_t{63};                 // every item's slabs start on a 256-byte boundary
+  }
+  bp.total_floats = off;
+  return AGNN_OK;
+}
+}  // namespace
+
+extern "C" size_t agnn_wgrad_batch_workspace_bytes(int32_t n_items, const agnn_wgrad_item_t* items) {
+  BatchPlan bp;
+  if (batch_plan(n_items, items, bp) != AGNN_OK) return 0;
+  return bp.total_floats * sizeof(float) + 256;
+}
+
+extern "C" int agnn_wgrad_batch_f32(int32_t n_items, const agnn_wgrad_item_t* items, void* workspace, size_t workspace_bytes,
+                                    agnn_stream_t stream_) {
+  using namespace agnn;
+  BatchPlan bp;
+  if (int rc = batch_plan(n_items, items, bp)) return rc;
+  if (!workspace || workspace_bytes < bp.total_floats * sizeof(float) + 256) return fail(AGNN_ENOMEM, "wgrad_batch: workspace too small");
+  float* ws = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t{255});
+  WgBatch wb{};
+  RedBatch rb{};
+  wb.n = rb.n = n_items;
+  int wg = 0, red = 0;
+  for (int i = 0; i < n_items; ++i) {
+    const agnn_wgrad_item_t& it = items[i];
+    if ((it.out_f & 1) || (it.in_f & 1) || (it.ld_dy & 1) || (it.ld_x & 1) || (it.ld_dw & 1)) return fail(AGNN_EALIGN, "wgrad_batch: item %d: widths and leading dimensions must be even", i);
+    if (!it.dy || !it.x || !it.dw) return fail(AGNN_EINVAL, "wgrad_batch: item %d: null argument", i);
+    if ((reinterpret_cast<uintptr_t>(it.dy) | reinterpret_cast<uintptr_t>(it.x) | reinterpret_cast<uintptr_t>(it.dw) | reinterpret_cast<uintptr_t>(it.db)) & 7u)
+      return fail(AGNN_EALIGN, "wgrad_batch: item %d: pointers must be 8-byte aligned", i);
+    if (it.ld_dy < it.out_f || it.ld_x < it.in_f || it.ld_dw < it.in_f) return fail(AGNN_EINVAL, "wgrad_batch: item %d: leading dimension smaller than the width", i);
+    if ((static_cast<int64_t>(bp.rps[i]) + 128) * (it.ld_dy > it.ld_x ? it.ld_dy : it.ld_x) * 4 >= (int64_t{1} << 32))
+      return fail(AGNN_EINVAL, "wgrad_batch: item %d: a row slice (%d rows x ld) exceeds the kernel's 32-bit byte offsets", i, bp.rps[i]);
+    const int out_pad = bp.tiles_out[i] * 128, in_pad = bp.tiles_in[i] * 128;
+    float* slab = ws + bp.slab_off[i];
+    float* slab_b = ws + bp.slabb_off[i];
+    wb.it[i] = WgArgs{it.dy, it.x, it.ld_dy, it.ld_x, static_cast<int32_t>(it.n), it.out_f, it.in_f, bp.rps[i], bp.tiles_in[i], slab,
+                      it.db ? slab_b : nullptr, out_pad, in_pad};
+    wb.tiles[i] = bp.tiles_out[i] * bp.tiles_in[i];
+    wb.first[i] = wg;
+    wg += wb.tiles[i] * bp.S[i];
+    rb.it[i] = RedItem{slab, it.db ? slab_b : nullptr, it.dw, it.db, it.ld_dw, bp.S[i], it.out_f, it.in_f, out_pad, in_pad};
+    rb.first[i] = red;
+    int64_t blocks = (static_cast<int64_t>(it.out_f) * (it.in_f >> 1) + 31) / 32;
+    if (blocks > 1024) blocks = 1024;
+    red += static_cast<int>(blocks);
+  }
+  wb.first[n_items] = wg;
+  rb.first[n_items] = red;
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  hipLaunchKernelGGL(k_wgrad_batch, dim3(static_cast<unsigned>(wg)), dim3(256), 0, s, wb);
+  if (int rc = check_launch("wgrad_batch")) return rc;
+  hipLaunchKernelGGL(k_wgrad_reduce_batch, dim3(static_cast<unsigned>(red)), dim3(256), 0, s, rb);
+  return check_launch("wgrad_batch(reduce)");
 }

@@ -11,7 +11,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .linear import all_steal, defer, defer_home, deferring, leaf_refs, mark_wgrad_async, weight_grad, wgrad_stream
+from .linear import (WgItem, all_steal, defer, defer_home, deferring, leaf_refs, mark_wgrad_async, weight_grad, weight_grad_batch,
+                     wgrad_stream)
 
 KERNEL_HIDDEN = (64, 128)      # hidden sizes per direction the kernels are instantiated for (H = 128 / 256 hybrid models)
 
@@ -74,8 +75,9 @@ class _GRULayer(torch.autograd.Function):
         hp = torch.empty((B, T, 2, Hh), dtype=torch.float32, device=dev)                 # h_{t-1} per direction, one launch
 
         def weight_grads():
+            items = []
             if I % 2 == 0:
-                weight_grad(dgi2, x2, True, dw_out=dw_ih, db_out=db_ih)
+                items.append(WgItem(dgi2, x2, True, dw_ih, db_ih))
             else:                               # odd input width: the kernel pads a column, results are copied into place
                 dw, db = weight_grad(dgi2, x2, True)
                 dw_ih.copy_(dw)
@@ -83,7 +85,8 @@ class _GRULayer(torch.autograd.Function):
             _lib.check(lib.agnn_gru_hprev_f32(y.data_ptr(), B, T, Hh, hp.data_ptr(), _lib.stream_ptr(dev)), "agnn_gru_hprev_f32")
             dgh2, hp2 = dgh.view(B * T, 6 * Hh), hp.view(B * T, 2 * Hh)
             for d in range(2):
-                weight_grad(dgh2[:, d * 3 * Hh:(d + 1) * 3 * Hh], hp2[:, d * Hh:(d + 1) * Hh], True, dw_out=dw_hh[d], db_out=db_hh[d])
+                items.append(WgItem(dgh2[:, d * 3 * Hh:(d + 1) * 3 * Hh], hp2[:, d * Hh:(d + 1) * Hh], True, dw_hh[d], db_hh[d]))
+            weight_grad_batch(items)            # the layer's three products in one launch pair
 
         # off the chain only while every parameter behind the stacked operands takes its gradient over without a kernel
         # (no .grad yet, no hook): otherwise AccumulateGrad adds on this stream at once and must find the values there

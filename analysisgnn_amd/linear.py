@@ -199,13 +199,23 @@ def defer_home(fn, dev, tensors=()) -> bool:
     return True
 
 
+def _run_deferred(fns) -> None:
+    """The weight-gradient products of the list first, TOGETHER (`weight_grad_batch`: one launch pair per 16 of them), then the
+    other closures in their order — those only consume weight gradients (the SAGE layers' per-relation fan-out), never feed one."""
+    items = [f for f in fns if isinstance(f, WgItem)]
+    if items:
+        weight_grad_batch(items)
+    for fn in fns:
+        if not isinstance(fn, WgItem):
+            fn()
+
+
 def flush_deferred(dev=None) -> None:
     """Run, on the current stream, the closures that were deferred on it."""
     s = torch.cuda.current_stream(dev)
     entry = _DEFER["pending"].pop((s.device.index, s.cuda_stream), None)
     if entry is not None:
-        for fn in entry[1]:
-            fn()
+        _run_deferred(entry[1])
         join_later(s)                    # whoever gathers the gradients waits for this stream (a no-op for its own)
 
 
@@ -215,8 +225,7 @@ def flush_all_deferred() -> None:
     for key in list(_DEFER["pending"]):
         s, fns = _DEFER["pending"].pop(key)
         with torch.cuda.stream(s):
-            for fn in fns:
-                fn()
+            _run_deferred(fns)
         if cur is not None and (s.device.index, s.cuda_stream) != (cur.device.index, cur.cuda_stream):
             torch.cuda.current_stream(s.device).wait_stream(s)
 
@@ -284,6 +293,63 @@ def weight_grad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool, dw_out: Opti
     return (dw if in_k == in_f else dw[:, :in_f].contiguous()), db
 
 
+class WgItem:
+    """One pending weight-gradient product dW = dY^T X (+ db) with its destinations: what a projection's backward leaves behind
+    under dp.defer_weight_grads instead of a closure, so that the flush can issue all of them in one launch pair."""
+    __slots__ = ("dy", "x", "want_bias", "dw_out", "db_out")
+
+    def __init__(self, dy, x, want_bias, dw_out, db_out):
+        self.dy, self.x, self.want_bias, self.dw_out, self.db_out = dy, x, bool(want_bias), dw_out, db_out
+
+    def __call__(self):
+        weight_grad(self.dy, self.x, self.want_bias, dw_out=self.dw_out, db_out=self.db_out)
+
+
+BATCH = True             # A/B switch for benchmarking: False = one launch pair per product, as in round 2
+
+
+def weight_grad_batch(items) -> None:
+    """`WgItem`s in as few launches as possible: those the MFMA kernel takes (fp32, even widths, >= MIN_ROWS rows, output up to
+    MAX_OUT_IN, results written in place) go to `agnn_wgrad_batch_f32` in groups of up to 16, the rest one by one."""
+    lib = None
+    group = []
+
+    def fits(it):
+        n, out_f = it.dy.shape
+        in_f = it.x.shape[1]
+        return (BATCH and ENABLED and it.dy.is_cuda and it.dy.dim() == 2 and it.x.dim() == 2 and n >= MIN_ROWS and out_f * in_f <= MAX_OUT_IN and in_f % 2 == 0
+                and _ok(it.dy) and _ok(it.x) and it.dw_out is not None and tuple(it.dw_out.shape) == (out_f, in_f) and it.dw_out.is_contiguous()
+                and it.dw_out.data_ptr() % 8 == 0 and (not it.want_bias or (it.db_out is not None and it.db_out.is_contiguous() and it.db_out.data_ptr() % 8 == 0)))
+
+    def run(group):
+        if len(group) == 1:
+            group[0]()
+            return
+        nonlocal lib
+        lib = lib or _lib.load()
+        dev = group[0].dy.device
+        arr = (_lib.WgradItem * len(group))()
+        for a, it in zip(arr, group):
+            a.dy, a.x, a.dw = it.dy.data_ptr(), it.x.data_ptr(), it.dw_out.data_ptr()
+            a.db = it.db_out.data_ptr() if it.want_bias else None
+            a.ld_dy, a.ld_x, a.ld_dw, a.n = it.dy.stride(0), it.x.stride(0), it.dw_out.stride(0), it.dy.shape[0]
+            a.out_f, a.in_f = it.dy.shape[1], it.x.shape[1]
+        nws = int(lib.agnn_wgrad_batch_workspace_bytes(len(group), arr))
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        _lib.check(lib.agnn_wgrad_batch_f32(len(group), arr, ws.data_ptr(), nws, _lib.stream_ptr(dev)), "agnn_wgrad_batch_f32")
+
+    for it in items:
+        if fits(it):
+            group.append(it)
+            if len(group) == _lib.WGRAD_BATCH_MAX:
+                run(group)
+                group = []
+        else:
+            it()
+    if group:
+        run(group)
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, acc):
@@ -313,7 +379,7 @@ class _LinearFn(torch.autograd.Function):
             dw = torch.empty((dy.shape[1], x.shape[1]), dtype=torch.float32, device=dy.device)
             db = torch.empty((dy.shape[1],), dtype=torch.float32, device=dy.device) if want_b else None
             dw_k, db_k = dw.detach(), (db.detach() if db is not None else None)
-            defer(lambda: weight_grad(dy, x, want_b, dw_out=dw_k, db_out=db_k), dy.device)
+            defer(WgItem(dy, x, want_b, dw_k, db_k), dy.device)
         elif want_w:
             # forked before dX is queued: both start at once — only when the gradients will be STOLEN (no kernel on the main stream)
             with wgrad_stream(dy.device, dy, x, active=steals):

@@ -108,8 +108,8 @@ class TorchAnalysisGNN(nn.Module):
     # (one clean graph break at the boundary instead of one per kernel call).
     # Data-parallel steps (dp.FlatGradBuffer(late=model.late_parameters())): with `split_backward = True` the autograd graph is
     # cut behind the input layers, `loss.backward()` ends there — every gradient but theirs exists and can be all-reduced —
-    # and `finish_backward()` runs the input layers' backward beside the collective.  Same kernels, same order: the
-    # gradients are bit-identical to the unsplit step.
+    # and `finish_backward()` runs the input layers' backward beside the collective.  Same kernels, same order; the gradients
+    # equal the unsplit step's to fp32 rounding (deferred weight-gradient products are batched per flush: the groups differ).
     split_backward = False
 
     def late_parameters(self):

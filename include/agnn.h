@@ -356,6 +356,21 @@ size_t agnn_wgrad_workspace_bytes(int64_t n, int32_t out_f, int32_t in_f);
 int agnn_wgrad_f32(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, int64_t n, int32_t out_f,
                    int32_t in_f, float* dw, int64_t ld_dw, float* db, void* workspace, size_t workspace_bytes,
                    agnn_stream_t stream);
+/* Several weight gradients in ONE launch pair (product kernel + slab reduction): the items' workgroups fill the chip together, so
+ * every item gets by with a few row slices instead of up to 64 (fewer slabs written and read back, longer K loops) and the
+ * step's ~20 reduction launches become one per group.  Same arithmetic per item as agnn_wgrad_f32 with that slice count
+ * (deterministic; the slice count — hence the summation order — depends on the group's composition).  At most 16 items. */
+typedef struct {
+  const float* dy;   /* (device) [n, out_f], leading dimension ld_dy */
+  const float* x;    /* (device) [n, in_f],  leading dimension ld_x  */
+  float* dw;         /* (device) out [out_f, in_f], leading dimension ld_dw */
+  float* db;         /* (device) out [out_f] or NULL */
+  int64_t ld_dy, ld_x, ld_dw, n;
+  int32_t out_f, in_f;
+} agnn_wgrad_item_t;
+size_t agnn_wgrad_batch_workspace_bytes(int32_t n_items, const agnn_wgrad_item_t* items /* (host) */);
+int agnn_wgrad_batch_f32(int32_t n_items, const agnn_wgrad_item_t* items /* (host) */, void* workspace, size_t workspace_bytes,
+                         agnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Batched small 2-D gather / sum, one launch for many parameter-sized pieces:

@@ -7,6 +7,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+def _same_to_rounding(a, b, what=""):
+    """Deferred weight gradients are issued TOGETHER at the flush points (linear.weight_grad_batch): the same products, but the
+    number of row slices a product is cut into — the summation order — depends on what else is pending, so schedules that group
+    them differently agree to fp32 rounding, not bit for bit.  2e-6 of the largest magnitude."""
+    a, b = a.detach().double(), b.detach().double()
+    err, scale = float((a - b).abs().max()), float(b.abs().max())
+    assert err <= 2e-6 * scale + 1e-12, f"{what}: {err:.3e} vs scale {scale:.3e}"
+
+
 @pytest.mark.parametrize("defer", [False, True])
 def test_graph_replay_equals_eager_step_and_is_reproducible(defer):
     """`defer`: the projections' weight gradients leave their place in the backward pass and run at the flush points of the
@@ -54,7 +63,9 @@ def test_graph_replay_equals_eager_step_and_is_reproducible(defer):
                 loss_d = fwd_bwd()
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize()
-            assert float(loss_d) == l_eager and torch.equal(flat.flat, g_eager)
+            assert float(loss_d) == l_eager
+            _same_to_rounding(flat.flat, g_eager, "deferred vs plain schedule")
+            g_eager = flat.flat.clone()          # what the captured (deferred) step must reproduce BIT FOR BIT
         cg = torch.cuda.CUDAGraph()
         with torch.cuda.graph(cg):
             loss_g = fwd_bwd()
@@ -79,7 +90,8 @@ def test_graph_replay_equals_eager_step_and_is_reproducible(defer):
 def test_deferred_weight_gradients_on_ragged_sampled_batch(late):
     """dp.defer_weight_grads with both backward schedules of the hybrid encoder (the sequence branch behind a late-created node
     / in autograd order) on a neighbour-sampled batch whose three subgraphs have DIFFERENT lengths (padded sequences, every
-    layer trimmed, the last one without edges): loss and every gradient bit-identical to the plain step."""
+    layer trimmed, the last one without edges): the loss identical, every gradient equal to the plain step's to fp32 rounding (the
+    deferred products are issued as one batch: another summation order), the deferred step itself reproducible bit for bit."""
     from analysisgnn_amd import dp, encoders, graph
     from analysisgnn_amd.heads import MultiTaskLoss, training_loss
     from analysisgnn_amd.models import TorchAnalysisGNN
@@ -115,7 +127,10 @@ def test_deferred_weight_gradients_on_ragged_sampled_batch(late):
         encoders.LATE_SEQUENCE_BACKWARD = late
         dp.defer_weight_grads(True)
         l1, g1 = fwd_bwd()
-        assert l1 == l0 and torch.equal(g1, g0), float((g1 - g0).abs().max())
+        assert l1 == l0
+        _same_to_rounding(g1, g0, "deferred vs plain schedule")
+        l2, g2 = fwd_bwd()
+        assert l2 == l1 and torch.equal(g2, g1)               # the deferred schedule itself is reproducible bit for bit
     finally:
         dp.defer_weight_grads(False)
         dp.enable_wgrad_overlap(False)
@@ -238,7 +253,7 @@ def test_existing_grads_with_deferred_and_overlapped_weight_grads(mode):
     """with dp.defer_weight_grads / enable_wgrad_overlap a gradient may only be produced late (or on the weight-
     gradient stream) while its parameter has no `.grad` — otherwise AccumulateGrad adds at once, on the main stream.  The
     guard looks through the cats / stacks / packs of parameters (linear.all_steal).  Two micro-batches accumulated into
-    `.grad`, and FlatGradBuffer(views=True) (gradients pre-set as views): bit-identical to the plain schedule."""
+    `.grad`, and FlatGradBuffer(views=True) (gradients pre-set as views): equal to the plain schedule to fp32 rounding."""
     from analysisgnn_amd import dp, graph
     from analysisgnn_amd.heads import MultiTaskLoss, training_loss
     from analysisgnn_amd.linear import join_wgrad
@@ -284,7 +299,7 @@ def test_existing_grads_with_deferred_and_overlapped_weight_grads(mode):
         g1 = run(True)
         assert all(torch.isfinite(t).all() for t in g0) and max(float(t.abs().max()) for t in g0) > 0
         for a, b, (name, _) in zip(g0, g1, both.named_parameters()):
-            assert torch.equal(a, b), (name, float((a - b).abs().max()))
+            _same_to_rounding(b, a, name)
     finally:
         dp.defer_weight_grads(False)
         dp.enable_wgrad_overlap(False)
@@ -331,7 +346,8 @@ def test_nested_wgrad_stream_inside_a_capture():
 def test_split_backward_two_buckets_equal_the_unsplit_step():
     """N > 1 schedule of bench.py on one rank: the autograd graph cut behind the input layers (models.split_backward), the
     gradient buffer in two buckets (dp.plan_parameters(late=...), pack("early") / finish_backward / pack("late")).  Same kernels
-    in the same order: every gradient bit-identical to the one-message step; the late bucket holds exactly the input layers."""
+    in the same order (the deferred weight-gradient products grouped differently: equal to fp32 rounding); the late bucket holds
+    exactly the input layers."""
     from analysisgnn_amd import dp, graph
     from analysisgnn_amd.heads import MultiTaskLoss, training_loss
     from analysisgnn_amd.models import TorchAnalysisGNN
@@ -378,7 +394,7 @@ def test_split_backward_two_buckets_equal_the_unsplit_step():
         g1, l1 = run(True)
         assert l0 == l1
         for n in g0:
-            assert torch.equal(g0[n], g1[n]), n
+            _same_to_rounding(g1[n], g0[n], n)
     finally:
         model.split_backward = False
         dp.defer_weight_grads(False)
