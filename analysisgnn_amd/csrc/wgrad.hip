@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgArgs a) { wgrad_tile(a, blockId
 // needs up to 64 row slices to put a workgroup on every CU — 64 slabs written and read back per output, a 250-row K loop per
 // workgroup, and a reduction launch of its own (20 x ~11 us per step).  The deferred weight gradients (dp.defer_weight_grads) are
 // pending TOGETHER at the encoder's flush points, so they are issued together: the workgroups of all items fill the chip, every
-// item gets by with the same few slices (640 / total tiles: 6 at the GNN stack's flush), K loops of thousands of rows, and ONE
+// item gets by with the same few slices (384 / total tiles: 5 at the GNN stack's flush), K loops of thousands of rows, and ONE
 // reduction launch serves all outputs.
 constexpr int kWgBatchMax = 16;
 
@@ -326,7 +326,9 @@ struct BatchPlan {
   size_t slab_off[kWgBatchMax], slabb_off[kWgBatchMax], total_floats;
 };
 
-// one slice count for the whole batch: ~2.5 workgroups per CU over all items together, K loops of >= 64 rows
+// one slice count for the whole batch: ~1.5 workgroups per CU over all items together, K loops of >= 64 rows.  The target was swept
+// inside the training step (c2s, two runs each on one box): 256 -> 3.39 ms, 320 -> 3.27, 384 -> 3.19, 448 -> 3.28, 512 -> 3.29,
+// 640 -> 3.21, 896 -> 3.22, 1280 -> 3.26 (one launch pair per product, as in round 2: 3.34)
 int batch_plan(int n_items, const agnn_wgrad_item_t* items, BatchPlan& bp) {
   using namespace agnn;
   if (n_items <= 0 || n_items > kWgBatchMax || !items) return fail(AGNN_EINVAL, "wgrad_batch: %d items (1 .. %d)", n_items, kWgBatchMax);
@@ -339,7 +341,7 @@ int batch_plan(int n_items, const agnn_wgrad_item_t* items, BatchPlan& bp) {
     bp.tiles_in[i] = (it.in_f + 127) / 128;
     tiles += static_cast<int64_t>(bp.tiles_out[i]) * bp.tiles_in[i];
   }
-  int64_t S = 640 / tiles;
+  int64_t S = 384 / tiles;
   if (S > 64) S = 64;
   if (S < 1) S = 1;
   size_t off = 0;
