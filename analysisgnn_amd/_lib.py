@@ -68,6 +68,11 @@ class WgradItem(C.Structure):
                 ("ld_dw", C.c_int64), ("n", C.c_int64), ("out_f", C.c_int32), ("in_f", C.c_int32)]
 
 
+class ColsumItem(C.Structure):
+    _fields_ = [("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("n", C.c_int64), ("H", C.c_int32), ("dgamma", C.c_void_p),
+                ("dbeta", C.c_void_p)]
+
+
 WGRAD_BATCH_MAX = 16
 PACK_MAX_SRC = 8
 
@@ -140,6 +145,7 @@ SIGNATURES = {
     "agnn_norm_act_bwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float,
                                         C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "agnn_norm_act_colsum_batch_f32": (C.c_int, [C.c_int32, C.POINTER(ColsumItem), C.c_void_p]),
     "agnn_skip_act_workspace_bytes": (C.c_size_t, []),
     "agnn_skip_act_fwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_uint32,
                                         C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

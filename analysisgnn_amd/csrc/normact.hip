@@ -256,11 +256,11 @@ __global__ __launch_bounds__(256) void k_na_bwd(NaArgs a, const float* __restric
 }
 
 // dgamma[j] | dbeta[j] = sum over blocks of part[b][j | H + j].  Block = 32 columns x 32 partial sums (fixed order).
-__global__ __launch_bounds__(1024) void k_na_colsum(const float* __restrict__ part, int n_rows, int width, float* __restrict__ dgamma,
-                                                    float* __restrict__ dbeta, int H) {
+__device__ __forceinline__ void na_colsum_block(const float* __restrict__ part, int n_rows, int width, float* __restrict__ dgamma,
+                                                float* __restrict__ dbeta, int H, const int block) {
   __shared__ float sm[32][33];
   const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int j = blockIdx.x * 32 + col;
+  const int j = block * 32 + col;
   float s = 0.f;
   if (j < width) {
     // all 32 loads of a pass are in flight together (the slab has just been written: L2 / MALL hits); a chain of
@@ -410,6 +410,28 @@ __global__ __launch_bounds__(256) void k_mix_bwd(MixArgs a, const float* __restr
   }
 }
 
+__global__ __launch_bounds__(1024) void k_na_colsum(const float* __restrict__ part, int n_rows, int width, float* __restrict__ dgamma,
+                                                    float* __restrict__ dbeta, int H) {
+  na_colsum_block(part, n_rows, width, dgamma, dbeta, H, blockIdx.x);
+}
+
+// several pending column sums in one launch (they only feed the optimizer and are pending together at the flush points)
+constexpr int kColsumBatchMax = 16;
+struct ColsumBatch {
+  const float* part[kColsumBatchMax];
+  float* dgamma[kColsumBatchMax];
+  float* dbeta[kColsumBatchMax];
+  int32_t n_rows[kColsumBatchMax], H[kColsumBatchMax], first[kColsumBatchMax + 1];
+  int32_t n;
+};
+
+__global__ __launch_bounds__(1024) void k_na_colsum_batch(ColsumBatch b) {
+  int i = 0;
+  const int blk = blockIdx.x;
+  while (i + 1 < b.n && blk >= b.first[i + 1]) ++i;
+  na_colsum_block(b.part[i], b.n_rows[i], 2 * b.H[i], b.dgamma[i], b.dbeta[i], b.H[i], blk - b.first[i]);
+}
+
 constexpr int kBwdBlocks = 1024;    // 4 waves per SIMD; partial slab = 1024 * 2H floats (one row per block)
 
 int na_check(const char* who, const void* x, int64_t ld_x, const void* gamma, const void* beta, int64_t n, int32_t H, int32_t seg,
@@ -546,4 +568,30 @@ extern "C" int agnn_skip_act_bwd_f32(const float* x, int64_t ld_x, const float* 
   float* part = workspace ? reinterpret_cast<float*>(static_cast<char*>(workspace) + 256) : nullptr;
   AGNN_NA_DISPATCH(k_mix_bwd, a, dz, ld_dz, dx, ld_dx, dout, ld_do, part, ticket, dskip);
   return check_launch("skip_act_bwd");
+}
+
+extern "C" int agnn_norm_act_colsum_batch_f32(int32_t n_items, const agnn_colsum_item_t* items, agnn_stream_t stream_) {
+  using namespace agnn;
+  if (n_items <= 0 || n_items > kColsumBatchMax || !items) return fail(AGNN_EINVAL, "norm_act_colsum_batch: %d items (1 .. %d)", n_items, kColsumBatchMax);
+  ColsumBatch b{};
+  b.n = n_items;
+  int blocks = 0;
+  for (int i = 0; i < n_items; ++i) {
+    const agnn_colsum_item_t& it = items[i];
+    if (it.n <= 0 || it.H <= 0 || (it.H & 3) || it.H > 2048 || !it.workspace || !it.dgamma || !it.dbeta)
+      return fail(AGNN_EINVAL, "norm_act_colsum_batch: item %d: bad sizes or null argument", i);
+    if (it.workspace_bytes < agnn_norm_act_workspace_bytes(it.H)) return fail(AGNN_ENOMEM, "norm_act_colsum_batch: item %d: workspace too small", i);
+    int nb = static_cast<int>((it.n + 3) / 4);
+    if (nb > kBwdBlocks) nb = kBwdBlocks;
+    b.part[i] = static_cast<const float*>(it.workspace);
+    b.dgamma[i] = it.dgamma;
+    b.dbeta[i] = it.dbeta;
+    b.n_rows[i] = nb;
+    b.H[i] = it.H;
+    b.first[i] = blocks;
+    blocks += (2 * it.H + 31) / 32;
+  }
+  b.first[n_items] = blocks;
+  hipLaunchKernelGGL(k_na_colsum_batch, dim3(blocks), dim3(1024), 0, static_cast<hipStream_t>(stream_), b);
+  return check_launch("norm_act_colsum_batch");
 }

@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .linear import all_steal, defer, deferring, leaf_refs
+from .linear import ColsumItem, all_steal, defer, deferring, leaf_refs
 
 PRE_RELU, POST_RELU = 1, 2
 ENABLED = True
@@ -88,8 +88,7 @@ class _NormAct(torch.autograd.Function):
                    "agnn_norm_act_bwd_f32")
         if later:
             dg_k, db_k = dgamma.detach(), dbeta.detach()
-            defer(lambda: _lib.check(lib.agnn_norm_act_colsum_f32(ws.data_ptr(), nws, n, H, dg_k.data_ptr(), db_k.data_ptr(),
-                                                                  _lib.stream_ptr(dev)), "agnn_norm_act_colsum_f32"), dev)
+            defer(ColsumItem(ws, n, H, dg_k, db_k), dev)       # pending column sums of a flush go out in one launch
         return dx, dgamma, dbeta, None, None, None, None, None, None, None
 
 

@@ -203,11 +203,15 @@ def _run_deferred(fns) -> None:
     """The weight-gradient products of the list first, TOGETHER (`weight_grad_batch`: one launch pair per 16 of them), then the
     other closures in their order — those only consume weight gradients (the SAGE layers' per-relation fan-out), never feed one."""
     items = [f for f in fns if isinstance(f, WgItem)]
-    if items:
-        weight_grad_batch(items)
-    for fn in fns:
-        if not isinstance(fn, WgItem):
-            fn()
+    sums = [f for f in fns if isinstance(f, ColsumItem)]
+    with torch.no_grad():                # a flush may run outside a backward pass (FlatGradBuffer.pack): gradient math, never recorded
+        if items:
+            weight_grad_batch(items)
+        if sums:
+            colsum_batch(sums)
+        for fn in fns:
+            if not isinstance(fn, (WgItem, ColsumItem)):
+                fn()
 
 
 def flush_deferred(dev=None) -> None:
@@ -303,6 +307,33 @@ class WgItem:
 
     def __call__(self):
         weight_grad(self.dy, self.x, self.want_bias, dw_out=self.dw_out, db_out=self.db_out)
+
+
+class ColsumItem:
+    """One pending LayerNorm dgamma / dbeta column sum (fused._NormAct.backward under dp.defer_weight_grads)."""
+    __slots__ = ("ws", "n", "H", "dgamma", "dbeta")
+
+    def __init__(self, ws, n, H, dgamma, dbeta):
+        self.ws, self.n, self.H, self.dgamma, self.dbeta = ws, int(n), int(H), dgamma, dbeta
+
+    def __call__(self):
+        _lib.check(_lib.load().agnn_norm_act_colsum_f32(self.ws.data_ptr(), self.ws.numel(), self.n, self.H, self.dgamma.data_ptr(),
+                                                        self.dbeta.data_ptr(), _lib.stream_ptr(self.ws.device)), "agnn_norm_act_colsum_f32")
+
+
+def colsum_batch(items) -> None:
+    if not BATCH or len(items) == 1:
+        for it in items:
+            it()
+        return
+    lib = _lib.load()
+    for i in range(0, len(items), _lib.WGRAD_BATCH_MAX):
+        grp = items[i:i + _lib.WGRAD_BATCH_MAX]
+        arr = (_lib.ColsumItem * len(grp))()
+        for a, it in zip(arr, grp):
+            a.workspace, a.workspace_bytes, a.n, a.H = it.ws.data_ptr(), it.ws.numel(), it.n, it.H
+            a.dgamma, a.dbeta = it.dgamma.data_ptr(), it.dbeta.data_ptr()
+        _lib.check(lib.agnn_norm_act_colsum_batch_f32(len(grp), arr, _lib.stream_ptr(grp[0].ws.device)), "agnn_norm_act_colsum_batch_f32")
 
 
 BATCH = True             # A/B switch for benchmarking: False = one launch pair per product, as in round 2

@@ -77,6 +77,7 @@ def parse_args(argv=None):
     ap.add_argument("--schedule", default="auto", choices=["auto", "late", "plain"],
                     help="backward schedule of the hybrid encoders: capture both and keep the faster (auto), or force one")
     ap.add_argument("--no-defer", action="store_true", help="A/B only: weight gradients where they are computed, not deferred")
+    ap.add_argument("--defer-all", action="store_true", help="A/B only: deferred (batched) weight gradients for MetricalGNN too")
     ap.add_argument("--no-wgrad-overlap", action="store_true", help="A/B only: weight gradients on the main stream")
     ap.add_argument("--wgrad-scope", default="sequence", help="A/B only: kinds of weight-gradient work on the side stream")
     ap.add_argument("--library-wgrad", action="store_true", help="A/B only: weight gradients through the library GEMM")
@@ -338,7 +339,7 @@ def main():
     dp.enable_wgrad_overlap(not args.no_wgrad_overlap and args.workload in ("c2", "c2s"), args.wgrad_scope.split(","))
     # dW / db of the projections on the main stream wait until that stream has slack (the GNN stack's backward is done, the
     # sequence branch's is not): the hybrid encoders only
-    dp.defer_weight_grads(not args.no_defer and enc in ("hybridgnn", "hgt"))
+    dp.defer_weight_grads(not args.no_defer and (enc in ("hybridgnn", "hgt") or args.defer_all))
     opt = dp.FlatAdamW(params, flat, lr=5e-3, weight_decay=5e-3)     # analysis.py:1380-1381 hyper-parameters
     graph.index_cache_enabled = False                               # fresh batch every step: rebuild the CSR
 

@@ -327,6 +327,18 @@ int agnn_norm_act_bwd_f32(const float* x, int64_t ld_x, const float* gamma, cons
 /* agnn_norm_act_bwd_f32 with dgamma == dbeta == NULL leaves the per-block partial sums in `workspace` and launches only the
  * input-gradient kernel; this entry point turns them into dgamma / dbeta later (same n, H, workspace): the two parameter
  * gradients only feed the optimizer and need not sit on the backward pass's dependent chain. */
+/* Several pending column sums (agnn_norm_act_colsum_f32) in one launch: they only feed the optimizer and are pending together at
+ * the encoder's flush points.  At most 16 items. */
+typedef struct {
+  const void* workspace;   /* what agnn_norm_act_bwd_f32 (dgamma == dbeta == NULL) left */
+  size_t workspace_bytes;
+  int64_t n;
+  int32_t H;
+  float* dgamma;
+  float* dbeta;
+} agnn_colsum_item_t;
+int agnn_norm_act_colsum_batch_f32(int32_t n_items, const agnn_colsum_item_t* items /* (host) */, agnn_stream_t stream);
+
 /* HGT layer epilogue in one launch each way (round 3):  z = dropout_p( relu?( x + sigmoid(*skip) * (o - x) ) )  — PyG HGTConv's
  * learnable skip connection (alpha = sigmoid(skip[node type])) followed by the ReLU + dropout the encoders put between layers
  * (graphmuse HybridHGT via models/analysis.py:445-453).  x == skip == NULL: no skip connection, z = act(o).  flags bit 0 = ReLU.
