@@ -183,7 +183,7 @@ template <int HH>
 __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, const float* __restrict__ y,
                                                  const float* __restrict__ saved, const float* __restrict__ w_hh,
                                                  int T, float* __restrict__ dgi, float* __restrict__ dgh_out,
-                                                 const float* __restrict__ drop, float use) {
+                                                 const float* __restrict__ drop, float use, float* __restrict__ hp_out) {
   __shared__ __attribute__((aligned(16))) float dgh[3 * HH];
   __shared__ __attribute__((aligned(16))) float cpart[KC * HH];
   constexpr int CSTR = HH;
@@ -275,6 +275,7 @@ __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, co
     ho[0] = drp;
     ho[HH] = dzp;
     ho[2 * HH] = dq;
+    if (hp_out != nullptr) hp_out[(bt * 2 + d) * HH + u] = in.hp;      // h_{t-1}: the W_hh weight gradient's right operand, no extra pass
     fetch(s + 2, in);                    // refill this register set
   };
   StepIn inA, inB;
@@ -343,7 +344,7 @@ extern "C" int agnn_gru_fwd_f32(const float* gi, const float* w_hh, const float*
 }
 
 extern "C" int agnn_gru_bwd_f32(const float* dy, const float* y, const float* saved, const float* w_hh, int64_t B,
-                                int64_t T, int32_t hidden, float* dgi, float* dgh, const float* drop_scale,
+                                int64_t T, int32_t hidden, float* dgi, float* dgh, const float* drop_scale, float* hprev,
                                 agnn_stream_t stream_) {
   using namespace agnn;
   if (hidden != 128 && hidden != 64) return fail(AGNN_EINVAL, "gru_bwd: hidden=%d unsupported (this build: 64, 128)", hidden);
@@ -353,9 +354,9 @@ extern "C" int agnn_gru_bwd_f32(const float* dy, const float* y, const float* sa
   if (!aligned16(dy) || !aligned16(y) || !aligned16(saved) || !aligned16(w_hh) || !aligned16(dgi) || !aligned16(dgh)) return fail(AGNN_EALIGN, "gru_bwd: pointers must be 16-byte aligned");
   if (hidden == 128)
     hipLaunchKernelGGL(k_gru_bwd<128>, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), dy, y, saved, w_hh,
-                       static_cast<int>(T), dgi, dgh, drop_scale ? drop_scale : y, drop_scale ? 1.f : 0.f);
+                       static_cast<int>(T), dgi, dgh, drop_scale ? drop_scale : y, drop_scale ? 1.f : 0.f, hprev);
   else
     hipLaunchKernelGGL(k_gru_bwd<64>, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), dy, y, saved, w_hh,
-                       static_cast<int>(T), dgi, dgh, drop_scale ? drop_scale : y, drop_scale ? 1.f : 0.f);
+                       static_cast<int>(T), dgi, dgh, drop_scale ? drop_scale : y, drop_scale ? 1.f : 0.f, hprev);
   return check_launch("gru_bwd");
 }

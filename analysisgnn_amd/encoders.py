@@ -259,8 +259,11 @@ _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     if idx not in _SIDE_STREAMS:
-        _SIDE_STREAMS[idx] = torch.cuda.Stream(device=dev)
+        _SIDE_STREAMS[idx] = torch.cuda.Stream(device=dev, priority=SIDE_STREAM_PRIORITY)
     return _SIDE_STREAMS[idx]
+
+
+SIDE_STREAM_PRIORITY = 0        # A/B switch (bench.py --side-priority): -1 = the sequence branch's stream ahead of the main one
 
 
 LATE_SEQUENCE_BACKWARD = True   # the sequence branch behind a late-created node (_LateNode); bench.py --schedule measures both

@@ -59,9 +59,10 @@ class _GRULayer(torch.autograd.Function):
         dy = dy.contiguous()
         dgi = torch.empty((B, T, 2, 3 * Hh), dtype=torch.float32, device=dev)
         dgh = torch.empty((B, T, 2, 3 * Hh), dtype=torch.float32, device=dev)      # (d r_pre, d z_pre, d n_pre * r)
+        hp = torch.empty((B, T, 2, Hh), dtype=torch.float32, device=dev)                 # h_{t-1} per direction: left by the walk itself
         lib = _lib.load()
         _lib.check(lib.agnn_gru_bwd_f32(dy.data_ptr(), y.data_ptr(), saved.data_ptr(), w_hh.data_ptr(), B, T, Hh,
-                                        dgi.data_ptr(), dgh.data_ptr(), _lib.ptr(drop_scale), _lib.stream_ptr(dev)), "agnn_gru_bwd_f32")
+                                        dgi.data_ptr(), dgh.data_ptr(), _lib.ptr(drop_scale), hp.data_ptr(), _lib.stream_ptr(dev)), "agnn_gru_bwd_f32")
         dgi2 = dgi.view(B * T, 6 * Hh)
         wf = w_ih.reshape(6 * Hh, I)
         dx = (dgi2 @ wf).view(B, T, I) if ctx.needs_input_grad[0] else None
@@ -72,7 +73,6 @@ class _GRULayer(torch.autograd.Function):
         db_ih = torch.empty((6 * Hh,), dtype=torch.float32, device=dev)
         dw_hh = torch.empty((2, 3 * Hh, Hh), dtype=torch.float32, device=dev)            # both directions land in the stacked
         db_hh = torch.empty((2, 3 * Hh), dtype=torch.float32, device=dev)                # gradients directly (no torch.stack)
-        hp = torch.empty((B, T, 2, Hh), dtype=torch.float32, device=dev)                 # h_{t-1} per direction, one launch
 
         def weight_grads():
             items = []
@@ -82,7 +82,6 @@ class _GRULayer(torch.autograd.Function):
                 dw, db = weight_grad(dgi2, x2, True)
                 dw_ih.copy_(dw)
                 db_ih.copy_(db)
-            _lib.check(lib.agnn_gru_hprev_f32(y.data_ptr(), B, T, Hh, hp.data_ptr(), _lib.stream_ptr(dev)), "agnn_gru_hprev_f32")
             dgh2, hp2 = dgh.view(B * T, 6 * Hh), hp.view(B * T, 2 * Hh)
             for d in range(2):
                 items.append(WgItem(dgh2[:, d * 3 * Hh:(d + 1) * 3 * Hh], hp2[:, d * Hh:(d + 1) * Hh], True, dw_hh[d], db_hh[d]))

@@ -158,12 +158,22 @@ def deferring(t: torch.Tensor) -> bool:
     return bool(_DEFER["on"] and t.is_cuda)
 
 
-def defer(fn, dev) -> None:
+def defer(fn, dev, here: bool = False) -> None:
     """Queue optimizer-only work on the CURRENT stream's list: it runs at that stream's flush.  (Sending a branch stream's
     projections to the main chain's flush instead — `defer_home` — measured slower, 3.46 vs 3.39 ms at C2; only the inner
     recurrent layers' weight gradients go that way, because they must run beside the next layer's recurrence.)"""
     s = torch.cuda.current_stream(dev)
+    home = _DEFER.get("home")
+    if ITEMS_HOME and not here and isinstance(fn, (WgItem, ColsumItem)) and home is not None and (home.device.index, home.cuda_stream) != (s.device.index, s.cuda_stream):
+        # a branch stream's batchable product joins the main chain's next flush (one launch with that chain's own products)
+        fn.event = torch.cuda.Event()
+        fn.event.record(s)
+        defer_on(home, fn)
+        return
     _DEFER["pending"].setdefault((s.device.index, s.cuda_stream), (s, []))[1].append(fn)
+
+
+ITEMS_HOME = True        # A/B switch (bench.py --no-items-home): 3.22 -> 3.19 ms at C2 (two alternating pairs on one box)
 
 
 def defer_on(stream, fn) -> None:
@@ -204,6 +214,14 @@ def _run_deferred(fns) -> None:
     other closures in their order — those only consume weight gradients (the SAGE layers' per-relation fan-out), never feed one."""
     items = [f for f in fns if isinstance(f, WgItem)]
     sums = [f for f in fns if isinstance(f, ColsumItem)]
+    foreign = [f for f in items + sums if f.event is not None]
+    if foreign:                          # handed over from another stream: wait for their operands, keep those alive for this stream
+        here = torch.cuda.current_stream(foreign[0].tensors()[0].device)
+        for f in foreign:
+            here.wait_event(f.event)
+            for t in f.tensors():
+                if t is not None:
+                    t.record_stream(here)
     with torch.no_grad():                # a flush may run outside a backward pass (FlatGradBuffer.pack): gradient math, never recorded
         if items:
             weight_grad_batch(items)
@@ -300,10 +318,13 @@ def weight_grad(dy: torch.Tensor, x: torch.Tensor, want_bias: bool, dw_out: Opti
 class WgItem:
     """One pending weight-gradient product dW = dY^T X (+ db) with its destinations: what a projection's backward leaves behind
     under dp.defer_weight_grads instead of a closure, so that the flush can issue all of them in one launch pair."""
-    __slots__ = ("dy", "x", "want_bias", "dw_out", "db_out")
+    __slots__ = ("dy", "x", "want_bias", "dw_out", "db_out", "event")
 
     def __init__(self, dy, x, want_bias, dw_out, db_out):
-        self.dy, self.x, self.want_bias, self.dw_out, self.db_out = dy, x, bool(want_bias), dw_out, db_out
+        self.dy, self.x, self.want_bias, self.dw_out, self.db_out, self.event = dy, x, bool(want_bias), dw_out, db_out, None
+
+    def tensors(self):
+        return (self.dy, self.x, self.dw_out, self.db_out)
 
     def __call__(self):
         weight_grad(self.dy, self.x, self.want_bias, dw_out=self.dw_out, db_out=self.db_out)
@@ -311,10 +332,13 @@ class WgItem:
 
 class ColsumItem:
     """One pending LayerNorm dgamma / dbeta column sum (fused._NormAct.backward under dp.defer_weight_grads)."""
-    __slots__ = ("ws", "n", "H", "dgamma", "dbeta")
+    __slots__ = ("ws", "n", "H", "dgamma", "dbeta", "event")
 
     def __init__(self, ws, n, H, dgamma, dbeta):
-        self.ws, self.n, self.H, self.dgamma, self.dbeta = ws, int(n), int(H), dgamma, dbeta
+        self.ws, self.n, self.H, self.dgamma, self.dbeta, self.event = ws, int(n), int(H), dgamma, dbeta, None
+
+    def tensors(self):
+        return (self.ws, self.dgamma, self.dbeta)
 
     def __call__(self):
         _lib.check(_lib.load().agnn_norm_act_colsum_f32(self.ws.data_ptr(), self.ws.numel(), self.n, self.H, self.dgamma.data_ptr(),
@@ -404,13 +428,20 @@ class _LinearFn(torch.autograd.Function):
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         steals = ctx.wg_async and all_steal(ctx.steal_refs)     # gradients taken over without a kernel on this stream
-        if want_w and steals and ctx.wg_defer and x.shape[1] % 2 == 0 and deferring(dy):
+        in_f = x.shape[1]
+        padded = bool(in_f & 1) and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) > in_f     # a spare zero column behind the last one
+        if want_w and steals and ctx.wg_defer and (in_f % 2 == 0 or padded) and deferring(dy):
             # only dX stays here.  The closure fills aliases: a second reference to `dw` itself would make AccumulateGrad
             # CLONE it (now, before it is computed) instead of taking it over.
-            dw = torch.empty((dy.shape[1], x.shape[1]), dtype=torch.float32, device=dy.device)
+            dw = torch.empty((dy.shape[1], in_f), dtype=torch.float32, device=dy.device)
             db = torch.empty((dy.shape[1],), dtype=torch.float32, device=dy.device) if want_b else None
             dw_k, db_k = dw.detach(), (db.detach() if db is not None else None)
-            defer(WgItem(dy, x, want_b, dw_k, db_k), dy.device)
+            if padded:                   # the product runs on in + 1 columns (models.encode's 281-wide note input); its first `in` are copied out
+                dw_wide = torch.empty((dy.shape[1], in_f + 1), dtype=torch.float32, device=dy.device)
+                defer(WgItem(dy, x.as_strided((x.shape[0], in_f + 1), (x.stride(0), 1), x.storage_offset()), want_b, dw_wide, db_k), dy.device, here=True)       # stays with its copy
+                defer(lambda: dw_k.copy_(dw_wide[:, :in_f]), dy.device)
+            else:
+                defer(WgItem(dy, x, want_b, dw_k, db_k), dy.device)
         elif want_w:
             # forked before dX is queued: both start at once — only when the gradients will be STOLEN (no kernel on the main stream)
             with wgrad_stream(dy.device, dy, x, active=steals):

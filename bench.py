@@ -79,6 +79,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-defer", action="store_true", help="A/B only: weight gradients where they are computed, not deferred")
     ap.add_argument("--defer-all", action="store_true", help="A/B only: deferred (batched) weight gradients for MetricalGNN too")
     ap.add_argument("--no-wgrad-overlap", action="store_true", help="A/B only: weight gradients on the main stream")
+    ap.add_argument("--items-home", default="auto", choices=["auto", "on", "off"],
+                    help="a branch stream's deferred weight-gradient products: with the main chain's flush (on) / on the branch's own (off) / measured (auto)")
+    ap.add_argument("--side-priority", type=int, default=0, help="A/B only: HIP priority of the sequence branch's stream (-1 = high)")
     ap.add_argument("--wgrad-scope", default="sequence", help="A/B only: kinds of weight-gradient work on the side stream")
     ap.add_argument("--library-wgrad", action="store_true", help="A/B only: weight gradients through the library GEMM")
     ap.add_argument("--blas", default=None, choices=[None, "hipblaslt", "rocblas"], help="A/B only: torch's preferred BLAS library")
@@ -340,6 +343,11 @@ def main():
     # dW / db of the projections on the main stream wait until that stream has slack (the GNN stack's backward is done, the
     # sequence branch's is not): the hybrid encoders only
     dp.defer_weight_grads(not args.no_defer and (enc in ("hybridgnn", "hgt") or args.defer_all))
+    from analysisgnn_amd import encoders as _enc0
+    _enc0.SIDE_STREAM_PRIORITY = args.side_priority
+    from analysisgnn_amd import linear as _lin
+    if args.items_home != "auto":
+        _lin.ITEMS_HOME = args.items_home == "on"
     opt = dp.FlatAdamW(params, flat, lr=5e-3, weight_decay=5e-3)     # analysis.py:1380-1381 hyper-parameters
     graph.index_cache_enabled = False                               # fresh batch every step: rebuild the CSR
 
@@ -407,13 +415,17 @@ def main():
             dot = args.graph_dot                                 # the captured step's dependency graph as DOT (debugging)
             # Which of the two backward schedules of the hybrid encoders replays faster depends on how many nodes each
             # branch of the captured graph has (profiles/r02_step_timeline.md: c2s 3.39 vs 3.45 ms, c2 3.61 vs 3.54 ms), so
-            # both are captured and the faster one (6 replays each, slowest rank decides) is kept — TunableOp's way.
+            # both are captured and the faster one (40 replays each, slowest rank decides) is kept — TunableOp's way.  Same for
+            # where the sequence branch's deferred weight-gradient products run (linear.ITEMS_HOME: c2s 3.19 vs 3.22 ms with
+            # them in the main chain's flush, c2d 3.38 vs 3.35 — round 3, alternating pairs on one box).
             from analysisgnn_amd import encoders as _enc
-            tune = args.schedule == "auto" and enc in ("hybridgnn", "hgt") and not args.no_defer and not dot
-            variants = [True, False] if tune else [{"late": True, "plain": False, "auto": _enc.LATE_SEQUENCE_BACKWARD}[args.schedule]]
+            hybrid = enc in ("hybridgnn", "hgt") and not args.no_defer and not dot
+            lates = [True, False] if args.schedule == "auto" and hybrid else [{"late": True, "plain": False, "auto": _enc.LATE_SEQUENCE_BACKWARD}[args.schedule]]
+            homes = [True, False] if args.items_home == "auto" and hybrid else [_lin.ITEMS_HOME]
+            variants = [(a, b) for a in lates for b in homes]
             best = None
-            for late in variants:
-                _enc.LATE_SEQUENCE_BACKWARD = late
+            for late, home in variants:
+                _enc.LATE_SEQUENCE_BACKWARD, _lin.ITEMS_HOME = late, home
                 g1 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g1, capture_error_mode=cap_mode):
                     loss_v = fwd_bwd()
@@ -426,24 +438,26 @@ def main():
                         bwd_tail()
                 t_v = 0.0
                 if len(variants) > 1:
-                    g1.replay()
+                    for _ in range(5):
+                        g1.replay()
                     dp.barrier_and_sync()
                     t0 = time.perf_counter()
-                    for _ in range(6):
+                    for _ in range(40):
                         g1.replay()
                     dp.barrier_and_sync()
                     t_v = dp.max_over_ranks(time.perf_counter() - t0)
                 if best is None or t_v < best[0]:
-                    best = (t_v, g1, loss_v, late, gt)
-            _, g1, loss_ref[0], schedule_late, g_tail = best
-            _enc.LATE_SEQUENCE_BACKWARD = schedule_late
+                    best = (t_v, g1, loss_v, late, gt, home)
+            _, g1, loss_ref[0], schedule_late, g_tail, schedule_home = best
+            _enc.LATE_SEQUENCE_BACKWARD, _lin.ITEMS_HOME = schedule_late, schedule_home
             if rank == 0 and len(variants) > 1:
-                print(f"[bench] backward schedule: sequence branch {'behind a late node' if schedule_late else 'in autograd order'}",
-                      file=sys.stderr)
+                print(f"[bench] backward schedule: sequence branch {'behind a late node' if schedule_late else 'in autograd order'}, "
+                      f"its deferred products {'with the main flush' if schedule_home else 'on its own flush'}", file=sys.stderr)
             with torch.cuda.graph(g2, capture_error_mode=cap_mode):
                 update()
             graphs = (g1, g2, g_tail)
-            graph_mode = f"hipGraph replay (capture_error_mode={cap_mode})"
+            graph_mode = (f"hipGraph replay (capture_error_mode={cap_mode}; sequence branch {'late node' if schedule_late else 'autograd order'}, "
+                          f"its deferred products {'in the main flush' if schedule_home else 'in its own flush'})")
         except Exception as e:                                  # capture refused: run eagerly — a HOST-BOUND number, flagged at top level
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graphs = None

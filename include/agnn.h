@@ -195,8 +195,10 @@ int agnn_gru_fwd_f32(const float* gi, const float* w_hh, const float* b_hh, int6
                      int32_t hidden, float* y, float* saved, const float* drop_scale, float* y_drop,
                      agnn_stream_t stream);
 int agnn_gru_bwd_f32(const float* dy, const float* y, const float* saved, const float* w_hh,
-                     int64_t B, int64_t T, int32_t hidden, float* dgi, float* dgh, const float* drop_scale,
+                     int64_t B, int64_t T, int32_t hidden, float* dgi, float* dgh, const float* drop_scale, float* hprev,
                      agnn_stream_t stream);
+/* hprev (optional) [B, T, 2, hidden]: the backward walk reads h_{t-1} anyway and leaves it here — the right operand of the
+ * W_hh weight-gradient product (the same matrix agnn_gru_hprev_f32 builds in a pass of its own). */
 /* Inter-layer dropout of `nn.GRU(dropout=p)` (ref: models/cadence.py:249-251) rides along: drop_scale [B, T, 2*hidden]
  * holds 0 or 1 / (1 - p) per element; forward additionally writes y_drop = y * drop_scale (the next layer's input),
  * backward takes dy = d(y_drop) and applies the same factor.  Both NULL: no dropout. */

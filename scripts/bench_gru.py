@@ -40,5 +40,5 @@ def timed(fn, rep=10):
     return e0.elapsed_time(e1) / rep * 1e3
 f = timed(lambda: _lib.check(lib.agnn_gru_fwd_f32(gi.data_ptr(), w.data_ptr(), bh.data_ptr(), B, T, Hh, yy.data_ptr(), saved.data_ptr(), None, None, st), "fwd"))
 dyv = torch.randn_like(yy)
-bw = timed(lambda: _lib.check(lib.agnn_gru_bwd_f32(dyv.data_ptr(), yy.data_ptr(), saved.data_ptr(), w.data_ptr(), B, T, Hh, dgi.data_ptr(), dgh.data_ptr(), None, st), "bwd"))
+bw = timed(lambda: _lib.check(lib.agnn_gru_bwd_f32(dyv.data_ptr(), yy.data_ptr(), saved.data_ptr(), w.data_ptr(), B, T, Hh, dgi.data_ptr(), dgh.data_ptr(), None, None, st), "bwd"))
 print(f"B={B} T={T}: k_gru_fwd {f:.1f} us = {f / T:.3f} us/step ({f / T * 2400:.0f} cycles @2.4 GHz); k_gru_bwd {bw:.1f} us = {bw / T:.3f} us/step")

@@ -100,3 +100,29 @@ def test_inter_layer_dropout_rides_with_the_recurrence_kernels(B, T, I):
         b = gru_forward(m, x, training=True)
         c = gru_forward(m, x, training=False)
     assert not torch.equal(a, b) and not torch.equal(a, c)
+
+
+@pytest.mark.parametrize("B,T,hidden", [(1, 1, 128), (3, 37, 128), (4, 50, 64)])
+def test_backward_walk_leaves_previous_states(B, T, hidden):
+    """agnn_gru_bwd_f32's optional `hprev` output = the matrix agnn_gru_hprev_f32 builds from y (bit for bit: both copy y)."""
+    from analysisgnn_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g).to(DEV)                                 # noqa: E731
+    gi, w, b = r(B, T, 2, 3 * hidden), r(2, 3 * hidden, hidden) * 0.1, r(2, 3 * hidden)
+    y = torch.empty(B, T, 2 * hidden, device=DEV)
+    saved = torch.empty(B, T, 2, 4, hidden, device=DEV)
+    st = _lib.stream_ptr(torch.device(DEV))
+    _lib.check(lib.agnn_gru_fwd_f32(gi.data_ptr(), w.data_ptr(), b.data_ptr(), B, T, hidden, y.data_ptr(), saved.data_ptr(), None, None, st), "fwd")
+    dy = r(B, T, 2 * hidden)
+    dgi, dgh = torch.empty_like(gi), torch.empty_like(gi)
+    hp = torch.full((B, T, 2, hidden), float("nan"), device=DEV)
+    _lib.check(lib.agnn_gru_bwd_f32(dy.data_ptr(), y.data_ptr(), saved.data_ptr(), w.data_ptr(), B, T, hidden, dgi.data_ptr(),
+                                    dgh.data_ptr(), None, hp.data_ptr(), st), "bwd")
+    want = torch.empty_like(hp)
+    _lib.check(lib.agnn_gru_hprev_f32(y.data_ptr(), B, T, hidden, want.data_ptr(), st), "hprev")
+    assert torch.equal(hp, want)
+    dgi2, dgh2 = torch.empty_like(gi), torch.empty_like(gi)
+    _lib.check(lib.agnn_gru_bwd_f32(dy.data_ptr(), y.data_ptr(), saved.data_ptr(), w.data_ptr(), B, T, hidden, dgi2.data_ptr(),
+                                    dgh2.data_ptr(), None, None, st), "bwd without hprev")
+    assert torch.equal(dgi, dgi2) and torch.equal(dgh, dgh2)
