@@ -39,27 +39,32 @@ def _al16(t: torch.Tensor) -> torch.Tensor:
 
 class _NormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, p, flags, call_id, seg=0, defer_ok=False, steal_refs=None):
+    def forward(ctx, x, gamma, beta, eps, p, flags, call_id, seg=0, defer_ok=False, steal_refs=None, pre=None):
         """x [n, H]; gamma / beta [H]; statistics over segments of `seg` floats (0 = the whole row).  `defer_ok`: gamma / beta
-        are leaves, or reach their leaves through views only (their gradients may be produced late: linear.defer_weight_grads)."""
+        are leaves, or reach their leaves through views only (their gradients may be produced late: linear.defer_weight_grads).
+        `pre` = [y, mean, rstd] already computed by a fused producer (heads.fused_head_logits): nothing is launched here, the
+        node only carries the backward pass."""
         dev = _lib.require_gpu(x, gamma, beta)
         ctx.defer_ok = bool(defer_ok) or (gamma.is_leaf and beta.is_leaf)
         ctx.steal_refs = leaf_refs(gamma, beta) if steal_refs is None else tuple(steal_refs)   # reshaped operands: the caller names the leaves
         lib = _lib.load()
         x = x if (x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else x.contiguous()
         n, H = x.shape
-        y = torch.empty((n, H), dtype=torch.float32, device=dev)
         seg = int(seg) if seg else H
-        mean = torch.empty((max(n, 1) * (H // seg),), dtype=torch.float32, device=dev)
-        rstd = torch.empty((max(n, 1) * (H // seg),), dtype=torch.float32, device=dev)
         rng = rng_state(dev) if p > 0 else None
         # the (seed, step) pair this call draws from is saved with it: the live counter moves on with every training forward
         # (models.encode -> advance_rng), and backward must regenerate THIS call's masks
         used = torch.empty(2, dtype=torch.int64, device=dev) if p > 0 else None
         gamma, beta = _al16(gamma.contiguous()), _al16(beta.contiguous())
-        _lib.check(lib.agnn_norm_act_fwd_f32(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), seg, n, H, float(eps), float(p),
-                                             int(flags), _lib.ptr(rng), int(call_id), y.data_ptr(), y.stride(0), mean.data_ptr(),
-                                             rstd.data_ptr(), _lib.ptr(used), _lib.stream_ptr(dev)), "agnn_norm_act_fwd_f32")
+        if pre is not None:
+            y, mean, rstd = pre
+        else:
+            y = torch.empty((n, H), dtype=torch.float32, device=dev)
+            mean = torch.empty((max(n, 1) * (H // seg),), dtype=torch.float32, device=dev)
+            rstd = torch.empty((max(n, 1) * (H // seg),), dtype=torch.float32, device=dev)
+            _lib.check(lib.agnn_norm_act_fwd_f32(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), seg, n, H, float(eps), float(p),
+                                                 int(flags), _lib.ptr(rng), int(call_id), y.data_ptr(), y.stride(0), mean.data_ptr(),
+                                                 rstd.data_ptr(), _lib.ptr(used), _lib.stream_ptr(dev)), "agnn_norm_act_fwd_f32")
         ctx.save_for_backward(x, gamma, beta, mean, rstd, *([used] if used is not None else []))
         ctx.cfg = (float(eps), float(p), int(flags), int(call_id), seg)
         return y
@@ -89,7 +94,7 @@ class _NormAct(torch.autograd.Function):
         if later:
             dg_k, db_k = dgamma.detach(), dbeta.detach()
             defer(ColsumItem(ws, n, H, dg_k, db_k), dev)       # pending column sums of a flush go out in one launch
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 _MIX_WS: Dict[str, torch.Tensor] = {}
@@ -186,7 +191,7 @@ def norm_act(x: torch.Tensor, ln: nn.LayerNorm, pre_relu: bool = False, post_rel
     return y.view(x.shape)
 
 
-def grouped_norm_act(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, pre_relu: bool = False) -> torch.Tensor:
+def grouped_norm_act(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, pre_relu: bool = False, pre=None) -> torch.Tensor:
     """x [N, G, H] -> LayerNorm over H with per-group affine gamma/beta [G, H] (optionally ReLU first): the G task heads'
     `ReLU -> LayerNorm` of one note in ONE pass over the [N, G*H] row (segmented statistics, models/analysis.py:488-493)."""
     N, G, H = x.shape
@@ -194,11 +199,13 @@ def grouped_norm_act(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, e
     gl = H // 4
     ok = (ENABLED and x.is_cuda and x.dtype == torch.float32 and H % 4 == 0 and 256 % H == 0 and (gl & (gl - 1)) == 0 and W <= 2048)
     if not ok:
+        if pre is not None:
+            raise _lib.AgnnError("grouped_norm_act: precomputed results need the kernel path")
         y = F.relu(x) if pre_relu else x
         return F.layer_norm(y, (H,), None, None, eps) * gamma + beta
     view_only = all(t.is_leaf or getattr(t, "_agnn_wgrad_deferrable", False) for t in (gamma, beta))
     y = _NormAct.apply(x.reshape(N, W), gamma.reshape(W), beta.reshape(W), eps, 0.0, PRE_RELU if pre_relu else 0,
-                       next(_CALL_IDS) & 0xFFFFFFFF, H, view_only, leaf_refs(gamma, beta))
+                       next(_CALL_IDS) & 0xFFFFFFFF, H, view_only, leaf_refs(gamma, beta), pre)
     return y.view(N, G, H)
 
 

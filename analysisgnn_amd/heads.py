@@ -34,14 +34,24 @@ def fused_head_logits(clf_dict: nn.ModuleDict, x: torch.Tensor, tasks: Sequence[
     # the cats themselves are views when the parameters are adjacent in memory (dp.plan_parameters), launches otherwise
     W1 = _cat_params([m[0].weight for m in mods])                         # [T*h2, o]; the cat's backward only takes views
     b1 = _cat_params([m[0].bias for m in mods])
-    a = linear(x, W1, b1)                                                 # [N, T*h2]
     gamma = _cat_params([m[2].weight for m in mods], stack=True)          # [T, h2]; backward = views
     beta = _cat_params([m[2].bias for m in mods], stack=True)
-    a = grouped_norm_act(a.view(-1, T, h2), gamma, beta, mods[0][2].eps, pre_relu=True)   # ReLU + per-task LayerNorm, one launch
     offs = [0]
     for m in mods:
         offs.append(offs[-1] + m[3].out_features)
     b2 = _cat_params([m[3].bias for m in mods])
+    eps = mods[0][2].eps
+    if (HEADS_FUSED and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] == HEADS_IN and h2 == HEADS_HIDDEN
+            and T <= _lib.MAX_SEG and x.shape[0] > 0 and x.shape[0] * max(T * h2, offs[-1]) < 2 ** 30 - 2 ** 20):
+        # one launch computes everything (agnn_heads_fwd_f32); the three autograd nodes below are created around its results
+        # and only carry the backward pass
+        W2 = _cat_params([m[3].weight for m in mods])
+        z, y, mean, rstd, logits = heads_forward(x, W1, b1, gamma, beta, eps, W2, b2, offs, h2)
+        a = linear(x, W1, b1, pre=[z])
+        a = grouped_norm_act(a.view(-1, T, h2), gamma, beta, eps, pre_relu=True, pre=[y, mean, rstd])
+        return grouped_projection(a.reshape(-1, T * h2), W2, b2, offs, h2, pre=[logits]), offs
+    a = linear(x, W1, b1)                                                 # [N, T*h2]
+    a = grouped_norm_act(a.view(-1, T, h2), gamma, beta, eps, pre_relu=True)   # ReLU + per-task LayerNorm, one launch
     a = a.reshape(-1, T * h2)
     if a.is_cuda and h2 in GPROJ_K and T <= _lib.MAX_SEG and GPROJ_ENABLED:
         W2 = _cat_params([m[3].weight for m in mods])                     # [sum C, h2]
@@ -60,6 +70,41 @@ def _cat_params(ps, stack: bool = False) -> torch.Tensor:
     return mark_wgrad_async(t, deferrable=True, leaves=ps) if all(p.is_leaf for p in ps) else t
 
 
+HEADS_FUSED = False      # one launch for the whole head block (csrc/heads.hip).  Correct, but 148 us against 141 us for the three launches
+                         # at C2 (profiles/r03_heads.md: why) — off until it wins; bench.py --fused-heads switches it on for A/B runs
+HEADS_IN, HEADS_HIDDEN = 128, 64     # what agnn_heads_fwd_f32 is built for (the reference's out_channels = 128 models)
+_OFFS_HOST: dict = {}
+
+
+def heads_forward(x, W1, b1, gamma, beta, eps, W2, b2, offs, h2):
+    """(z, y, mean, rstd, logits) of the whole head block in one launch (csrc/heads.hip); operands are the stacked parameters."""
+    dev = _lib.require_gpu(x, W1, W2)
+    with torch.no_grad():
+        xc = x.detach()
+        xc = xc if (xc.stride(1) == 1 and xc.stride(0) % 4 == 0 and xc.data_ptr() % 16 == 0) else xc.contiguous()
+        al = lambda t: t if (t.is_contiguous() and t.data_ptr() % 16 == 0) else t.contiguous().clone()     # noqa: E731
+        w1, w2 = al(W1.detach()), al(W2.detach())
+        c = lambda t: t.detach().reshape(-1).contiguous()                                                  # noqa: E731
+        T = len(offs) - 1
+        N = xc.shape[0]
+        key = tuple(int(o) for o in offs)
+        oh = _OFFS_HOST.get(key)
+        if oh is None:
+            oh = _OFFS_HOST[key] = (_lib.C.c_int32 * len(key))(*key)
+        z = torch.empty((N, T * h2), dtype=torch.float32, device=dev)
+        y = torch.empty((N, T * h2), dtype=torch.float32, device=dev)
+        mean = torch.empty((N * T,), dtype=torch.float32, device=dev)
+        rstd = torch.empty((N * T,), dtype=torch.float32, device=dev)
+        logits = torch.empty((N, key[-1]), dtype=torch.float32, device=dev)
+        b2c = c(b2) if b2 is not None else None
+        _lib.check(_lib.load().agnn_heads_fwd_f32(xc.data_ptr(), xc.stride(0), N, xc.shape[1], h2, T, w1.data_ptr(), c(b1).data_ptr(),
+                                                  c(gamma).data_ptr(), c(beta).data_ptr(), float(eps), w2.data_ptr(), _lib.ptr(b2c),
+                                                  _offs_tensor(offs, dev).data_ptr(), oh, z.data_ptr(), y.data_ptr(), z.stride(0),
+                                                  mean.data_ptr(), rstd.data_ptr(), logits.data_ptr(), logits.stride(0),
+                                                  _lib.stream_ptr(dev)), "agnn_heads_fwd_f32")
+    return z, y, mean, rstd, logits
+
+
 GPROJ_K = (32, 64, 128)
 GPROJ_ENABLED = True     # A/B switch for benchmarking
 
@@ -74,7 +119,7 @@ def _offs_tensor(offs: Sequence[int], device) -> torch.Tensor:
 
 class _GroupedProj(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, w, b, offs_t, offs, K):
+    def forward(ctx, a, w, b, offs_t, offs, K, pre=None):
         dev = _lib.require_gpu(a, w, offs_t)
         ctx._wg_async_in = all(t is None or t.is_leaf or getattr(t, "_agnn_wgrad_async", False) for t in (w, b))
         ctx._wg_defer_in = all(t is None or t.is_leaf or getattr(t, "_agnn_wgrad_deferrable", False) for t in (w, b))
@@ -87,11 +132,14 @@ class _GroupedProj(torch.autograd.Function):
         sum_c = offs[-1]
         tiles = sum((offs[i + 1] - offs[i] + 31) // 32 for i in range(G))
         N = a.shape[0]
-        out = torch.empty((N, sum_c), dtype=torch.float32, device=dev)
-        lib = _lib.load()
-        bb = b.float().contiguous() if b is not None else None
-        _lib.check(lib.agnn_gproj_fwd_f32(a.data_ptr(), a.stride(0), w.data_ptr(), _lib.ptr(bb), offs_t.data_ptr(), G, K, tiles, N,
-                                          out.data_ptr(), out.stride(0), _lib.stream_ptr(dev)), "agnn_gproj_fwd_f32")
+        if pre is not None:                      # computed by the fused head kernel: this node only carries the backward pass
+            out = pre[0]
+        else:
+            out = torch.empty((N, sum_c), dtype=torch.float32, device=dev)
+            lib = _lib.load()
+            bb = b.float().contiguous() if b is not None else None
+            _lib.check(lib.agnn_gproj_fwd_f32(a.data_ptr(), a.stride(0), w.data_ptr(), _lib.ptr(bb), offs_t.data_ptr(), G, K, tiles, N,
+                                              out.data_ptr(), out.stride(0), _lib.stream_ptr(dev)), "agnn_gproj_fwd_f32")
         ctx.save_for_backward(a, w, offs_t)
         ctx.meta = (G, K, tiles, sum_c, b is not None)
         ctx.wg_async = ctx._wg_async_in
@@ -131,12 +179,12 @@ class _GroupedProj(torch.autograd.Function):
             _lib.check(lib.agnn_gproj_bwd_f32(dout.data_ptr(), dout.stride(0), a.data_ptr(), a.stride(0), w.data_ptr(),
                                               offs_t.data_ptr(), G, K, tiles, sum_c, N, da.data_ptr(), da.stride(0), None, None,
                                               None, 0, _lib.stream_ptr(dev)), "agnn_gproj_bwd_f32")
-        return da, dw, db, None, None, None
+        return da, dw, db, None, None, None, None
 
 
-def grouped_projection(a: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], offs: Sequence[int], K: int) -> torch.Tensor:
+def grouped_projection(a: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], offs: Sequence[int], K: int, pre=None) -> torch.Tensor:
     """out[:, offs[g]:offs[g+1]] = a[:, g*K:(g+1)*K] @ w[offs[g]:offs[g+1]].T + b[offs[g]:offs[g+1]]  for every group g."""
-    return _GroupedProj.apply(a, w, b, _offs_tensor(offs, a.device), tuple(int(o) for o in offs), int(K))
+    return _GroupedProj.apply(a, w, b, _offs_tensor(offs, a.device), tuple(int(o) for o in offs), int(K), pre)
 
 
 class _GroupedInProj(torch.autograd.Function):

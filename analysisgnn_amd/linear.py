@@ -407,13 +407,16 @@ def weight_grad_batch(items) -> None:
 
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, acc):
+    def forward(ctx, x, w, b, acc, pre=None):
+        """`pre` = [y]: the product was computed by a fused producer (heads.fused_head_logits) — the node only carries the backward pass."""
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         ctx.wg_async = _async_ok(w) and _async_ok(b)
         ctx.wg_defer = _deferrable(w) and _deferrable(b)
         ctx.steal_refs = leaf_refs(w, b)
         ctx.set_materialize_grads(False)          # an undefined output gradient (a structurally dead branch) stays undefined upstream
+        if pre is not None:
+            return pre[0]
         if acc is not None:                       # y = acc + x W^T (+ b): the GEMM's beta = 1 epilogue, no separate add
             y = torch.addmm(acc, x, w.t())
             return y + b if b is not None else y
@@ -422,7 +425,7 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         if dy is None:
-            return None, None, None, None
+            return None, None, None, None, None
         x, w = ctx.saved_tensors
         dw = db = None
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
@@ -447,11 +450,15 @@ class _LinearFn(torch.autograd.Function):
             with wgrad_stream(dy.device, dy, x, active=steals):
                 dw, db = weight_grad(dy, x, want_b)
         dx = dy @ w if ctx.needs_input_grad[0] else None
-        return dx, dw, db, (dy if ctx.needs_input_grad[3] else None)
+        return dx, dw, db, (dy if ctx.needs_input_grad[3] else None), None
 
 
-def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, acc: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x W^T (+ b) (+ acc)."""
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, acc: Optional[torch.Tensor] = None, pre=None) -> torch.Tensor:
+    """x W^T (+ b) (+ acc).  `pre` = [y]: already computed elsewhere (2-D x only) — only the autograd node is created."""
+    if pre is not None:
+        if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (b is not None and b.requires_grad)):
+            return _LinearFn.apply(x, w, b, None, pre)
+        return pre[0]
     if x.is_cuda and torch.is_grad_enabled() and (w.requires_grad or (b is not None and b.requires_grad)):
         if x.dim() == 2 and x.shape[0] >= MIN_ROWS:
             return _LinearFn.apply(x, w, b, acc)

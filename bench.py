@@ -81,6 +81,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-wgrad-overlap", action="store_true", help="A/B only: weight gradients on the main stream")
     ap.add_argument("--items-home", default="auto", choices=["auto", "on", "off"],
                     help="a branch stream's deferred weight-gradient products: with the main chain's flush (on) / on the branch's own (off) / measured (auto)")
+    ap.add_argument("--fused-heads", action="store_true", help="A/B only: the head block's forward in one launch (agnn_heads_fwd_f32)")
     ap.add_argument("--side-priority", type=int, default=0, help="A/B only: HIP priority of the sequence branch's stream (-1 = high)")
     ap.add_argument("--wgrad-scope", default="sequence", help="A/B only: kinds of weight-gradient work on the side stream")
     ap.add_argument("--library-wgrad", action="store_true", help="A/B only: weight gradients through the library GEMM")
@@ -346,6 +347,9 @@ def main():
     from analysisgnn_amd import encoders as _enc0
     _enc0.SIDE_STREAM_PRIORITY = args.side_priority
     from analysisgnn_amd import linear as _lin
+    if args.fused_heads:
+        from analysisgnn_amd import heads as _heads
+        _heads.HEADS_FUSED = True
     if args.items_home != "auto":
         _lin.ITEMS_HOME = args.items_home == "on"
     opt = dp.FlatAdamW(params, flat, lr=5e-3, weight_decay=5e-3)     # analysis.py:1380-1381 hyper-parameters

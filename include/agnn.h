@@ -431,6 +431,20 @@ int agnn_embed_cat_bwd_f32(const float* dout, int64_t ld_dout, int32_t col0, int
                            void* workspace, size_t workspace_bytes, agnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The task-head block in one launch (ref: models/analysis.py:486-496 `clf_dict[task] = Linear(o, o/2) -> ReLU ->
+ * LayerNorm(o/2) -> Linear(o/2, C_t)`, :546-548): for every task t
+ *     z_t = x W1_t^T + b1_t;   y_t = LayerNorm_t(ReLU(z_t));   logits[:, offs[t]:offs[t+1]] = y_t W2_t^T + b2_t
+ *   x [n_rows, in_f] (ld_x), w1 [T*hidden, in_f] / b1, gamma, beta [T*hidden] = the tasks' parameters stacked along rows,
+ *   w2 [sum_c, hidden] / b2 [sum_c] (b2 may be NULL), offs_dev DEVICE int32 [T+1], offs_host the same on the HOST (it sizes
+ *   the grid and deals the tasks to workgroups).  Written for the backward pass (agnn_norm_act_bwd_f32 with seg = hidden,
+ *   agnn_gproj_bwd_f32): z, y [n_rows, T*hidden] (ld_h), mean / rstd [n_rows, T].  This build: in_f = 128, hidden = 64, T <= 64.
+ * ------------------------------------------------------------------------------------------ */
+int agnn_heads_fwd_f32(const float* x, int64_t ld_x, int64_t n_rows, int32_t in_f, int32_t hidden, int32_t T, const float* w1,
+                       const float* b1, const float* gamma, const float* beta, float eps, const float* w2, const float* b2,
+                       const int32_t* offs_dev, const int32_t* offs_host, float* z, float* y, int64_t ld_h, float* mean,
+                       float* rstd, float* logits, int64_t ld_o, agnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Grouped projection: the last Linear(h2 -> C_t) of all task heads in one launch per direction
  * (ref: models/analysis.py:486-496 `clf_dict[task]`, :546-548).  Group g reads columns [g*K, (g+1)*K) of a and
  * owns output columns [seg_off[g], seg_off[g+1]) (the same side-by-side logits layout agnn_multitask_ce_f32 takes):

@@ -76,3 +76,32 @@ def r3_case(name):
     if not big:
         assert np.array_equal(I["x_dict"]["note"].numpy(), z["in.x_note"]) and np.array_equal(I["pitch_spelling"].numpy(), z["in.pitch_spelling"])
     return z, cfg, g, I, labels
+
+
+def assert_grads_close_or_relu_flips(names, hip_grads, tap64, loss64, plist, tol=1e-4, label="", max_flips=8):
+    """Gradients of the fp32 HIP path (`hip_grads`, in the order of `plist`) against the float64 graph that produced `loss64`
+    under `oracle.testing.ReluTap(keep_graph=True)`: each tensor within tol * max(1, |ref|max) — directly, or after removing
+    the exactly computed effect of ReLU derivatives that the fp32 evaluation flipped (inputs within rounding of the kink;
+    oracle.testing.explain_by_relu_flips, profiles/r03_parity_notes.md).  The flips found are printed, never tolerated blindly:
+    the deviation over ALL tensors at once must be a 0/1 combination of the flip directions."""
+    import torch
+    from oracle.testing import explain_by_relu_flips
+    g64 = torch.autograd.grad(loss64, plist, retain_graph=True, allow_unused=True)
+    bound = lambda ref: tol * max(1.0, float(ref.abs().max()))                        # noqa: E731
+    beyond = []
+    for k, gh, gr in zip(names, hip_grads, g64):
+        if gr is None:
+            assert gh is None or float(gh.abs().max()) == 0.0, k
+            continue
+        err = float((gh.detach().cpu().double() - gr).abs().max())
+        if err > bound(gr):
+            beyond.append((k, f"{err:.1e}"))
+    if not beyond:
+        return []
+    hip = [gh if gh is not None else torch.zeros_like(p) for gh, p in zip(hip_grads, plist)]
+    rep = explain_by_relu_flips(tap64, loss64, plist, hip, bound)
+    print(f"[{label}] {len(beyond)} gradient tensors beyond {tol:g} of float64 (e.g. {beyond[:3]}); {rep['n_candidates']} ReLU inputs near "
+          f"the kink examined, flipped on the HIP path: {rep['flips']}; worst residual after removing them: {rep['worst']}")
+    assert rep["ok"], f"{label}: gradient deviation is not explained by flipped ReLU derivatives: {rep['worst']}, coefficients {rep['coeffs']}"
+    assert 0 < len(rep["flips"]) <= max_flips, rep["flips"]
+    return rep["flips"]
