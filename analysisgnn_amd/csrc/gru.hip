@@ -12,6 +12,13 @@
 // fp32 throughout (v_exp/v_rcp gate functions, ~3 ulp), no atomics, bitwise reproducible run to run.
 #include "agnn_common.h"
 
+// The recurrence kernels are latency bound on VALU issue, and a wave that streams MFMAs starves the VALU instructions of the other
+// waves on its SIMD (scripts/mfma_valu_overlap_probe.py: 3.5 x slower) — in the training step the weight-gradient and library
+// GEMMs of the other branch run beside the recurrence and land on the same CUs.  Declaring v255 used makes every wave allocate 256
+// VGPRs: the workgroup's 8 waves (2 per SIMD) then own the whole register file of their CU and no other kernel's waves fit beside
+// them; the GEMMs take the other 192 CUs.  C2 step 3.215 -> 3.185 ms (profiles/r03_heads.md, two alternating pairs on one box).
+#define CLAIM_SIMD_REGISTERS() asm volatile("" ::: "v255")
+
 namespace {
 
 // hidden size per direction: template parameter HH of the kernels, 128 (H = 256 models: the C2 / C3 configurations) or 64
@@ -64,6 +71,7 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
   constexpr int CPW = HH / KC;           // columns of W_hh per wave (16 / 8)
   __shared__ __attribute__((aligned(16))) float hbuf[2][HH];
   __shared__ __attribute__((aligned(16))) float part[KC * PSTR];
+  CLAIM_SIMD_REGISTERS();
   const int b = blockIdx.x >> 1, d = blockIdx.x & 1;
   const int tid = threadIdx.x, lane = tid & 63;
   const int kc = __builtin_amdgcn_readfirstlane(tid >> 6);       // this WAVE's k chunk: its h values are wave-uniform
@@ -187,6 +195,7 @@ __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, co
   __shared__ __attribute__((aligned(16))) float dgh[3 * HH];
   __shared__ __attribute__((aligned(16))) float cpart[KC * HH];
   constexpr int CSTR = HH;
+  CLAIM_SIMD_REGISTERS();
   const int b = blockIdx.x >> 1, d = blockIdx.x & 1;
   const int tid = threadIdx.x;
   const int kc = __builtin_amdgcn_readfirstlane(tid >> 6);       // this WAVE's chunk of 48 rows j of W_hh: dgh[j] is wave-uniform
