@@ -152,15 +152,17 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
     const float hnew = (1.f - zz) * nn + zz * hprev;
     hprev = hnew;
     hbuf[cur ^ 1][u] = hnew;
+    const float y2v = hnew * fmaf(use, gin[3] - 1.f, 1.f);
+    load_gi(s + 4, gin);                 // refill this ring slot BEFORE the stores (one in-order counter for loads and stores:
+    __builtin_amdgcn_sched_barrier(0);   // a load behind this step's stores waits for their acknowledgement; see k_gru_bwd)
     const size_t bt = static_cast<size_t>(b) * T + t;
     y[bt * 2 * HH + d * HH + u] = hnew;
-    y2[bt * 2 * HH + d * HH + u] = hnew * fmaf(use, gin[3] - 1.f, 1.f);
+    y2[bt * 2 * HH + d * HH + u] = y2v;
     float* sv = saved + (bt * 2 + d) * 4 * HH + u;
     sv[0] = rr;
     sv[HH] = zz;
     sv[2 * HH] = nn;
     sv[3 * HH] = s2;
-    load_gi(s + 4, gin);                 // refill this ring slot
   };
   float g0[4], g1[4], g2[4], g3[4];
   load_gi(0, g0);
@@ -275,6 +277,12 @@ __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, co
     dgh[u] = drp;
     dgh[HH + u] = dzp;
     dgh[2 * HH + u] = dq;
+    const float hpv = in.hp;
+    // Refill this register set FIRST, then store: loads and stores share one in-order counter (vmcnt), so a load requested
+    // behind this step's 7 stores cannot be waited for before those stores are acknowledged — beside the other branch's
+    // weight-gradient traffic that took the recurrence from ~300 to 340 - 400 us per launch (profiles/r03_heads.md).
+    fetch(s + 4, in);
+    __builtin_amdgcn_sched_barrier(0);
     const size_t bt = static_cast<size_t>(b) * T + t;
     float* go = dgi + (bt * 2 + d) * 3 * HH + u;
     go[0] = drp;
@@ -284,18 +292,23 @@ __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, co
     ho[0] = drp;
     ho[HH] = dzp;
     ho[2 * HH] = dq;
-    if (hp_out != nullptr) hp_out[(bt * 2 + d) * HH + u] = in.hp;      // h_{t-1}: the W_hh weight gradient's right operand, no extra pass
-    fetch(s + 2, in);                    // refill this register set
+    if (hp_out != nullptr) hp_out[(bt * 2 + d) * HH + u] = hpv;        // h_{t-1}: the W_hh weight gradient's right operand, no extra pass
   };
-  StepIn inA, inB;
-  fetch(0, inA);
-  fetch(1, inB);
+  StepIn in0, in1, in2, in3;             // four time steps of operands in flight (two were not enough under memory load)
+  fetch(0, in0);
+  fetch(1, in1);
+  fetch(2, in2);
+  fetch(3, in3);
   int s = 0;
-  for (; s + 2 <= T; s += 2) {
-    phaseA(s, inA);     lds_barrier(); phaseB(); lds_barrier();
-    phaseA(s + 1, inB); lds_barrier(); phaseB(); lds_barrier();
+  for (; s + 4 <= T; s += 4) {
+    phaseA(s, in0);     lds_barrier(); phaseB(); lds_barrier();
+    phaseA(s + 1, in1); lds_barrier(); phaseB(); lds_barrier();
+    phaseA(s + 2, in2); lds_barrier(); phaseB(); lds_barrier();
+    phaseA(s + 3, in3); lds_barrier(); phaseB(); lds_barrier();
   }
-  if (s < T) { phaseA(s, inA); lds_barrier(); phaseB(); lds_barrier(); }
+  if (s < T)     { phaseA(s, in0);     lds_barrier(); phaseB(); lds_barrier(); }
+  if (s + 1 < T) { phaseA(s + 1, in1); lds_barrier(); phaseB(); lds_barrier(); }
+  if (s + 2 < T) { phaseA(s + 2, in2); lds_barrier(); phaseB(); lds_barrier(); }
 }
 
 // h_{t-1} of both directions as one [B*T, 2*HH] matrix — the left operand of the W_hh weight-gradient GEMMs:
