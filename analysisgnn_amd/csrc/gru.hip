@@ -71,6 +71,8 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
   constexpr int CPW = HH / KC;           // columns of W_hh per wave (16 / 8)
   __shared__ __attribute__((aligned(16))) float hbuf[2][HH];
   __shared__ __attribute__((aligned(16))) float part[KC * PSTR];
+  __shared__ float s_in[4][4][HH];        // ring of 4 steps: gi_r, gi_z, gi_n, dropout factor — written by the helper lanes
+  __shared__ float s_out[2][5][HH];       // the last two steps' y * factor, r, z, n, W_hn h + b_hn — written by phase 2
   CLAIM_SIMD_REGISTERS();
   const int b = blockIdx.x >> 1, d = blockIdx.x & 1;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
     }
   }
   if (tid < HH) { hbuf[0][tid] = 0.f; hbuf[1][tid] = 0.f; }
-  __syncthreads();
+  // (the one __syncthreads before the time loop sits in each role's branch, behind the helper lanes' first LDS writes)
 
   auto phase1 = [&](int cur) {
     f32x2 hk[CPW / 2];
@@ -109,12 +111,89 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
     }
   };
 
-  if (tid >= HH) {                       // waves 2..7: mat-vec only
-    for (int s = 0; s < T; ++s) {
-      phase1(s & 1);
-      lds_barrier();
-      lds_barrier();
+  // ---- roles.  The unit lanes (tid < HH: waves 0 and 1) touch LDS only; ALL global loads and stores of a step are done by
+  // helper lanes (tid 128 .. 128 + HH: waves 2 and 3, SIMDs that idle during phase 2) in the window where they would wait at the
+  // barrier: the input projections travel memory -> loader registers (two sets, requested 4 steps ahead) -> LDS ring `s_in` (2
+  // steps ahead) -> phase 2; the step's outputs travel phase 2 -> `s_out` -> helper -> memory one step later.  With the loads,
+  // stores and their address arithmetic inside phase 2 the step took 1 474 cycles, without them 1 310 (ablation, profiles/
+  // r03_gru.md) — and beside another kernel's memory traffic the unit lanes additionally waited for their stores to be
+  // acknowledged before a prefetched operand could be used (loads and stores share one in-order counter).
+  const bool loader = tid >= 128 && tid < 128 + HH;         // waves 2, 3: operands in
+  const bool storer = tid >= 384 && tid < 384 + HH;         // waves 6, 7 (the same SIMDs' second waves): results out
+  const int hu = tid - (loader ? 128 : 384);
+  const size_t row3 = static_cast<size_t>(2) * 3 * HH;
+  auto load_in = [&](int s_, float (&g3)[4]) {
+    const int sc = s_ < T ? s_ : T - 1;
+    const int t_ = d ? T - 1 - sc : sc;
+    const float* p = gi + (static_cast<size_t>(b) * T + t_) * row3 + static_cast<size_t>(d) * 3 * HH + hu;
+    g3[0] = p[0];
+    g3[1] = p[HH];
+    g3[2] = p[2 * HH];
+    g3[3] = fmaf(use, drop[(static_cast<size_t>(b) * T + t_) * 2 * HH + d * HH + hu] - 1.f, 1.f);       // the factor itself
+  };
+  auto put_in = [&](int s_, const float (&g3)[4]) {
+    float* q = &s_in[s_ & 3][0][hu];
+    q[0] = g3[0];
+    q[HH] = g3[1];
+    q[2 * HH] = g3[2];
+    q[3 * HH] = g3[3];
+  };
+  auto store_out = [&](int s_) {           // outputs of step s_ (>= 0): h_t from hbuf, the rest from sout
+    const int t = d ? T - 1 - s_ : s_;
+    const size_t bt = static_cast<size_t>(b) * T + t;
+    const float* o = &s_out[s_ & 1][0][hu];
+    y[bt * 2 * HH + d * HH + hu] = hbuf[(s_ + 1) & 1][hu];
+    y2[bt * 2 * HH + d * HH + hu] = o[0];
+    float* sv = saved + (bt * 2 + d) * 4 * HH + hu;
+    sv[0] = o[HH];
+    sv[HH] = o[2 * HH];
+    sv[2 * HH] = o[3 * HH];
+    sv[3 * HH] = o[4 * HH];
+  };
+
+  // window s = while the unit lanes run phase 2 of step s
+  if (loader) {                          // step s + 2's operands -> LDS, step s + 6's requested: four register sets in flight,
+    float g0[4], g1[4], g2[4], g3[4];    // ~2.4 us between request and use (two sets stalled the barrier beside the other
+    load_in(0, g0);                      // branch's weight-gradient traffic)
+    load_in(1, g1);
+    put_in(0, g0);
+    put_in(1, g1);
+    load_in(2, g2);
+    load_in(3, g3);
+    load_in(4, g0);
+    load_in(5, g1);
+    __syncthreads();
+    int s = 0;
+    for (; s + 4 <= T; s += 4) {
+      phase1(0); lds_barrier(); put_in(s + 2, g2); load_in(s + 6, g2); lds_barrier();
+      phase1(1); lds_barrier(); put_in(s + 3, g3); load_in(s + 7, g3); lds_barrier();
+      phase1(0); lds_barrier(); put_in(s + 4, g0); load_in(s + 8, g0); lds_barrier();
+      phase1(1); lds_barrier(); put_in(s + 5, g1); load_in(s + 9, g1); lds_barrier();
     }
+    if (s < T)     { phase1(0); lds_barrier(); put_in(s + 2, g2); lds_barrier(); }
+    if (s + 1 < T) { phase1(1); lds_barrier(); lds_barrier(); }
+    if (s + 2 < T) { phase1(0); lds_barrier(); lds_barrier(); }
+    return;
+  }
+  if (storer) {                          // step s - 1's outputs -> memory (window 0 stores step 0's slots with whatever LDS holds and
+    __syncthreads();                     // window 1 overwrites them: no branch around a memory operation in this loop — the compiler
+    int s = 0;                           // would wait for ALL outstanding operations at the join)
+    for (; s + 2 <= T; s += 2) {
+      phase1(0); lds_barrier(); store_out(s > 0 ? s - 1 : 0); lds_barrier();
+      phase1(1); lds_barrier(); store_out(s);                 lds_barrier();
+    }
+    if (s < T) { phase1(0); lds_barrier(); store_out(s > 0 ? s - 1 : 0); lds_barrier(); }
+    store_out(T - 1);
+    return;
+  }
+  if (tid >= HH) {                       // the other waves: mat-vec only
+    __syncthreads();
+    int s = 0;
+    for (; s + 2 <= T; s += 2) {
+      phase1(0); lds_barrier(); lds_barrier();
+      phase1(1); lds_barrier(); lds_barrier();
+    }
+    if (s < T) { phase1(0); lds_barrier(); lds_barrier(); }
     return;
   }
 
@@ -122,19 +201,7 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
   const int u = tid;
   const float bh0 = b_hh[d * 3 * HH + u], bh1 = b_hh[d * 3 * HH + HH + u], bh2 = b_hh[d * 3 * HH + 2 * HH + u];
   float hprev = 0.f;
-  const size_t row3 = static_cast<size_t>(2) * 3 * HH;
-  auto load_gi = [&](int s_, float (&g3)[4]) {
-    const int sc = s_ < T ? s_ : T - 1;
-    const int t_ = d ? T - 1 - sc : sc;
-    const float* p = gi + (static_cast<size_t>(b) * T + t_) * row3 + static_cast<size_t>(d) * 3 * HH + u;
-    g3[0] = p[0];
-    g3[1] = p[HH];
-    g3[2] = p[2 * HH];
-    g3[3] = drop[(static_cast<size_t>(b) * T + t_) * 2 * HH + d * HH + u];
-  };
-  auto phase2 = [&](int s, float (&gin)[4]) {
-    const int cur = s & 1;
-    const int t = d ? T - 1 - s : s;
+  auto phase2 = [&](int cur, int slot) {         // cur = s & 1, slot = s & 3: constants in the unrolled loop below
     float p0[KC], p1[KC], p2[KC];
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
@@ -142,43 +209,36 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
       p1[k] = part[k * PSTR + HH + u];
       p2[k] = part[k * PSTR + 2 * HH + u];
     }
+    const float* in = &s_in[slot][0][u];
+    const float gi0 = in[0], gi1 = in[HH], gi2 = in[2 * HH], fac = in[3 * HH];
     // fixed-shape tree (depth 3 instead of a chain of 8 dependent adds; same order every run: bitwise reproducible)
     const float s0 = (((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p0[4] + p0[5]) + (p0[6] + p0[7]))) + bh0;
     const float s1 = (((p1[0] + p1[1]) + (p1[2] + p1[3])) + ((p1[4] + p1[5]) + (p1[6] + p1[7]))) + bh1;
     const float s2 = (((p2[0] + p2[1]) + (p2[2] + p2[3])) + ((p2[4] + p2[5]) + (p2[6] + p2[7]))) + bh2;
-    const float rr = sigmoidf_(gin[0] + s0);
-    const float zz = sigmoidf_(gin[1] + s1);
-    const float nn = tanhf_(gin[2] + rr * s2);
+    const float rr = sigmoidf_(gi0 + s0);
+    const float zz = sigmoidf_(gi1 + s1);
+    const float nn = tanhf_(gi2 + rr * s2);
     const float hnew = (1.f - zz) * nn + zz * hprev;
     hprev = hnew;
     hbuf[cur ^ 1][u] = hnew;
-    const float y2v = hnew * fmaf(use, gin[3] - 1.f, 1.f);
-    load_gi(s + 4, gin);                 // refill this ring slot BEFORE the stores (one in-order counter for loads and stores:
-    __builtin_amdgcn_sched_barrier(0);   // a load behind this step's stores waits for their acknowledgement; see k_gru_bwd)
-    const size_t bt = static_cast<size_t>(b) * T + t;
-    y[bt * 2 * HH + d * HH + u] = hnew;
-    y2[bt * 2 * HH + d * HH + u] = y2v;
-    float* sv = saved + (bt * 2 + d) * 4 * HH + u;
-    sv[0] = rr;
-    sv[HH] = zz;
-    sv[2 * HH] = nn;
-    sv[3 * HH] = s2;
+    float* o = &s_out[cur][0][u];
+    o[0] = hnew * fac;
+    o[HH] = rr;
+    o[2 * HH] = zz;
+    o[3 * HH] = nn;
+    o[4 * HH] = s2;
   };
-  float g0[4], g1[4], g2[4], g3[4];
-  load_gi(0, g0);
-  load_gi(1, g1);
-  load_gi(2, g2);
-  load_gi(3, g3);
+  __syncthreads();
   int s = 0;
   for (; s + 4 <= T; s += 4) {
-    phase1(s & 1);       lds_barrier(); phase2(s, g0);     lds_barrier();
-    phase1((s + 1) & 1); lds_barrier(); phase2(s + 1, g1); lds_barrier();
-    phase1((s + 2) & 1); lds_barrier(); phase2(s + 2, g2); lds_barrier();
-    phase1((s + 3) & 1); lds_barrier(); phase2(s + 3, g3); lds_barrier();
+    phase1(0); lds_barrier(); phase2(0, 0); lds_barrier();
+    phase1(1); lds_barrier(); phase2(1, 1); lds_barrier();
+    phase1(0); lds_barrier(); phase2(0, 2); lds_barrier();
+    phase1(1); lds_barrier(); phase2(1, 3); lds_barrier();
   }
-  if (s < T)     { phase1(s & 1);       lds_barrier(); phase2(s, g0);     lds_barrier(); }
-  if (s + 1 < T) { phase1((s + 1) & 1); lds_barrier(); phase2(s + 1, g1); lds_barrier(); }
-  if (s + 2 < T) { phase1((s + 2) & 1); lds_barrier(); phase2(s + 2, g2); lds_barrier(); }
+  if (s < T)     { phase1(0); lds_barrier(); phase2(0, 0); lds_barrier(); }
+  if (s + 1 < T) { phase1(1); lds_barrier(); phase2(1, 1); lds_barrier(); }
+  if (s + 2 < T) { phase1(0); lds_barrier(); phase2(0, 2); lds_barrier(); }
 }
 
 // dy [B,T,2*HH]; y, saved from the forward; outputs dgi [B,T,2,3*HH] (d r_pre, d z_pre, d n_pre) and
@@ -189,13 +249,14 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
 //            by phase B of the previous step; gate gradients; dgi / dgh to HBM; the three dgh vectors to LDS;
 //   phase B (all 8 waves; wave = 48 rows of W_hh, lane = two hidden units): the wave's 48 dgh values from LDS (one
 //            address for all lanes), 48 packed FMAs, two partial sums to LDS.
-template <int HH>
+template <int HH, bool HP>
 __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, const float* __restrict__ y,
                                                  const float* __restrict__ saved, const float* __restrict__ w_hh,
                                                  int T, float* __restrict__ dgi, float* __restrict__ dgh_out,
                                                  const float* __restrict__ drop, float use, float* __restrict__ hp_out) {
-  __shared__ __attribute__((aligned(16))) float dgh[3 * HH];
+  __shared__ __attribute__((aligned(16))) float s_out[2][4][HH];      // per step parity: d r_pre | d z_pre | d n_pre * r | d n_pre
   __shared__ __attribute__((aligned(16))) float cpart[KC * HH];
+  __shared__ float s_in[4][6][HH];                                     // ring of 4 steps: dy * factor, r, z, n, W_hn h + b_hn, h_{t-1}
   constexpr int CSTR = HH;
   CLAIM_SIMD_REGISTERS();
   const int b = blockIdx.x >> 1, d = blockIdx.x & 1;
@@ -215,11 +276,10 @@ __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, co
     wb[j / 2] = f32x2{v0.y, v1.y};
   }
   for (int i = tid; i < KC * CSTR; i += NT) cpart[i] = 0.f;
-  __syncthreads();
 
-  auto phaseB = [&]() {
+  auto phaseB = [&](int cur) {
     f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
-    const float4* gp = reinterpret_cast<const float4*>(&dgh[JC * kc]);
+    const float4* gp = reinterpret_cast<const float4*>(&s_out[cur][0][0] + JC * kc);      // the first 3 HH floats: the dgh vector
 #pragma unroll
     for (int v = 0; v < JC / 4; ++v) {
       const float4 t4 = gp[v];
@@ -232,83 +292,139 @@ __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, co
     if (u_on) *reinterpret_cast<float2*>(&cpart[kc * CSTR + u0]) = make_float2(a0.x + a0.y, a1.x + a1.y);
   };
 
-  if (tid >= HH) {                       // waves 2..7: mat-vec only
-    for (int s = 0; s < T; ++s) {
-      lds_barrier();
-      phaseB();
-      lds_barrier();
-    }
-    return;
-  }
-
-  const int u = tid;
+  // ---- roles: as in k_gru_fwd.  Unit lanes (tid < HH) touch LDS only; helper lanes (tid 128 .. 128 + HH) move the operands
+  // memory -> registers (requested 4 steps ahead) -> `s_in` (2 steps ahead) and the gate gradients `s_out` -> memory one step
+  // later, in the window where they would wait for phase A.  h_{t-1} (the W_hh weight gradient's right operand) is copied to
+  // `hp_out` by the helper on the way in.  Step time 1 430 cycles with the 6 loads + 7 stores in phase A, 1 160 without.
+  const bool loader = tid >= 128 && tid < 128 + HH;         // waves 2, 3: operands in (and h_{t-1} out)
+  const bool storer = tid >= 384 && tid < 384 + HH;         // waves 6, 7: gate gradients out
+  const int hu = tid - (loader ? 128 : 384);
   struct StepIn { float dyv, r, z, n, q, hp; };
-  auto fetch = [&](int s_, StepIn& o) {
+  auto load_in = [&](int s_, StepIn& o) {
     const int sc = s_ < T ? s_ : T - 1;
     const int t_ = d ? sc : T - 1 - sc;          // reverse of the forward walk
     const int tp_ = d ? t_ + 1 : t_ - 1;
     const size_t bt_ = static_cast<size_t>(b) * T + t_;
-    o.dyv = dy[bt_ * 2 * HH + d * HH + u] * fmaf(use, drop[bt_ * 2 * HH + d * HH + u] - 1.f, 1.f);   // dy is d(y * drop)
-    const float* sv = saved + (bt_ * 2 + d) * 4 * HH + u;
+    o.dyv = dy[bt_ * 2 * HH + d * HH + hu] * fmaf(use, drop[bt_ * 2 * HH + d * HH + hu] - 1.f, 1.f);   // dy is d(y * drop)
+    const float* sv = saved + (bt_ * 2 + d) * 4 * HH + hu;
     o.r = sv[0];
     o.z = sv[HH];
     o.n = sv[2 * HH];
     o.q = sv[3 * HH];
     const bool has_prev = tp_ >= 0 && tp_ < T;
     const int tpc = has_prev ? tp_ : t_;
-    o.hp = y[(static_cast<size_t>(b) * T + tpc) * 2 * HH + d * HH + u] * (has_prev ? 1.f : 0.f);
+    o.hp = y[(static_cast<size_t>(b) * T + tpc) * 2 * HH + d * HH + hu] * (has_prev ? 1.f : 0.f);
   };
-  float dhz = 0.f;
-  auto phaseA = [&](int s, StepIn& in) {
-    const int t = d ? s : T - 1 - s;
-    float cp[KC];
-#pragma unroll
-    for (int k = 0; k < KC; ++k) cp[k] = cpart[k * CSTR + u];
-    const float carry = (((cp[0] + cp[1]) + (cp[2] + cp[3])) + ((cp[4] + cp[5]) + (cp[6] + cp[7]))) + dhz;   // fixed-shape tree
-    const float dh = in.dyv + carry;
-    const float dn = dh * (1.f - in.z);
-    const float dz = dh * (in.hp - in.n);
-    const float dnp = dn * (1.f - in.n * in.n);
-    const float dr = dnp * in.q;
-    const float dq = dnp * in.r;
-    const float dzp = dz * in.z * (1.f - in.z);
-    const float drp = dr * in.r * (1.f - in.r);
-    dhz = dh * in.z;
-    dgh[u] = drp;
-    dgh[HH + u] = dzp;
-    dgh[2 * HH + u] = dq;
-    const float hpv = in.hp;
-    // Refill this register set FIRST, then store: loads and stores share one in-order counter (vmcnt), so a load requested
-    // behind this step's 7 stores cannot be waited for before those stores are acknowledged — beside the other branch's
-    // weight-gradient traffic that took the recurrence from ~300 to 340 - 400 us per launch (profiles/r03_heads.md).
-    fetch(s + 4, in);
-    __builtin_amdgcn_sched_barrier(0);
+  auto put_in = [&](int s_, const StepIn& o) {
+    float* q = &s_in[s_ & 3][0][hu];
+    q[0] = o.dyv;
+    q[HH] = o.r;
+    q[2 * HH] = o.z;
+    q[3 * HH] = o.n;
+    q[4 * HH] = o.q;
+    q[5 * HH] = o.hp;
+    if (HP) {                                    // compile-time: no branch around a memory operation in the loop; a step index
+      const int sc = s_ < T ? s_ : T - 1;        // past the end repeats the last step's (identical) store
+      const int t_ = d ? sc : T - 1 - sc;
+      hp_out[((static_cast<size_t>(b) * T + t_) * 2 + d) * HH + hu] = o.hp;
+    }
+  };
+  auto store_out = [&](int s_) {
+    const int t = d ? s_ : T - 1 - s_;
     const size_t bt = static_cast<size_t>(b) * T + t;
-    float* go = dgi + (bt * 2 + d) * 3 * HH + u;
+    const float* o = &s_out[s_ & 1][0][hu];
+    const float drp = o[0], dzp = o[HH], dq = o[2 * HH], dnp = o[3 * HH];
+    float* go = dgi + (bt * 2 + d) * 3 * HH + hu;
     go[0] = drp;
     go[HH] = dzp;
     go[2 * HH] = dnp;
-    float* ho = dgh_out + (bt * 2 + d) * 3 * HH + u;
+    float* ho = dgh_out + (bt * 2 + d) * 3 * HH + hu;
     ho[0] = drp;
     ho[HH] = dzp;
     ho[2 * HH] = dq;
-    if (hp_out != nullptr) hp_out[(bt * 2 + d) * HH + u] = hpv;        // h_{t-1}: the W_hh weight gradient's right operand, no extra pass
   };
-  StepIn in0, in1, in2, in3;             // four time steps of operands in flight (two were not enough under memory load)
-  fetch(0, in0);
-  fetch(1, in1);
-  fetch(2, in2);
-  fetch(3, in3);
+
+  // window s = while the unit lanes run phase A of step s
+  if (loader) {                          // four register sets in flight: requested 6 steps ahead, to LDS 2 steps ahead
+    StepIn i0, i1, i2, i3;
+    load_in(0, i0);
+    load_in(1, i1);
+    put_in(0, i0);
+    put_in(1, i1);
+    load_in(2, i2);
+    load_in(3, i3);
+    load_in(4, i0);
+    load_in(5, i1);
+    __syncthreads();
+    int s = 0;
+    for (; s + 4 <= T; s += 4) {
+      put_in(s + 2, i2); load_in(s + 6, i2); lds_barrier(); phaseB(0); lds_barrier();
+      put_in(s + 3, i3); load_in(s + 7, i3); lds_barrier(); phaseB(1); lds_barrier();
+      put_in(s + 4, i0); load_in(s + 8, i0); lds_barrier(); phaseB(0); lds_barrier();
+      put_in(s + 5, i1); load_in(s + 9, i1); lds_barrier(); phaseB(1); lds_barrier();
+    }
+    if (s < T)     { put_in(s + 2, i2); lds_barrier(); phaseB(0); lds_barrier(); }
+    if (s + 1 < T) { lds_barrier(); phaseB(1); lds_barrier(); }
+    if (s + 2 < T) { lds_barrier(); phaseB(0); lds_barrier(); }
+    return;
+  }
+  if (storer) {
+    __syncthreads();
+    int s = 0;
+    for (; s + 2 <= T; s += 2) {
+      store_out(s > 0 ? s - 1 : 0); lds_barrier(); phaseB(0); lds_barrier();
+      store_out(s);                 lds_barrier(); phaseB(1); lds_barrier();
+    }
+    if (s < T) { store_out(s > 0 ? s - 1 : 0); lds_barrier(); phaseB(0); lds_barrier(); }
+    store_out(T - 1);
+    return;
+  }
+  if (tid >= HH) {                       // the other waves: mat-vec only
+    __syncthreads();
+    int s = 0;
+    for (; s + 2 <= T; s += 2) {
+      lds_barrier(); phaseB(0); lds_barrier();
+      lds_barrier(); phaseB(1); lds_barrier();
+    }
+    if (s < T) { lds_barrier(); phaseB(0); lds_barrier(); }
+    return;
+  }
+
+  const int u = tid;
+  float dhz = 0.f;
+  auto phaseA = [&](int cur, int slot) {         // cur = s & 1, slot = s & 3: constants in the unrolled loop below
+    float cp[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) cp[k] = cpart[k * CSTR + u];
+    const float* in = &s_in[slot][0][u];
+    const float dyv = in[0], r = in[HH], z = in[2 * HH], n = in[3 * HH], q = in[4 * HH], hp = in[5 * HH];
+    const float carry = (((cp[0] + cp[1]) + (cp[2] + cp[3])) + ((cp[4] + cp[5]) + (cp[6] + cp[7]))) + dhz;   // fixed-shape tree
+    const float dh = dyv + carry;
+    const float dn = dh * (1.f - z);
+    const float dz = dh * (hp - n);
+    const float dnp = dn * (1.f - n * n);
+    const float dr = dnp * q;
+    const float dq = dnp * r;
+    const float dzp = dz * z * (1.f - z);
+    const float drp = dr * r * (1.f - r);
+    dhz = dh * z;
+    float* o = &s_out[cur][0][u];
+    o[0] = drp;
+    o[HH] = dzp;
+    o[2 * HH] = dq;
+    o[3 * HH] = dnp;
+  };
+  __syncthreads();
   int s = 0;
   for (; s + 4 <= T; s += 4) {
-    phaseA(s, in0);     lds_barrier(); phaseB(); lds_barrier();
-    phaseA(s + 1, in1); lds_barrier(); phaseB(); lds_barrier();
-    phaseA(s + 2, in2); lds_barrier(); phaseB(); lds_barrier();
-    phaseA(s + 3, in3); lds_barrier(); phaseB(); lds_barrier();
+    phaseA(0, 0); lds_barrier(); phaseB(0); lds_barrier();
+    phaseA(1, 1); lds_barrier(); phaseB(1); lds_barrier();
+    phaseA(0, 2); lds_barrier(); phaseB(0); lds_barrier();
+    phaseA(1, 3); lds_barrier(); phaseB(1); lds_barrier();
   }
-  if (s < T)     { phaseA(s, in0);     lds_barrier(); phaseB(); lds_barrier(); }
-  if (s + 1 < T) { phaseA(s + 1, in1); lds_barrier(); phaseB(); lds_barrier(); }
-  if (s + 2 < T) { phaseA(s + 2, in2); lds_barrier(); phaseB(); lds_barrier(); }
+  if (s < T)     { phaseA(0, 0); lds_barrier(); phaseB(0); lds_barrier(); }
+  if (s + 1 < T) { phaseA(1, 1); lds_barrier(); phaseB(1); lds_barrier(); }
+  if (s + 2 < T) { phaseA(0, 2); lds_barrier(); phaseB(0); lds_barrier(); }
 }
 
 // h_{t-1} of both directions as one [B*T, 2*HH] matrix — the left operand of the W_hh weight-gradient GEMMs:
@@ -374,11 +490,14 @@ extern "C" int agnn_gru_bwd_f32(const float* dy, const float* y, const float* sa
   if (B == 0 || T == 0) return AGNN_OK;
   if (!dy || !y || !saved || !w_hh || !dgi || !dgh) return fail(AGNN_EINVAL, "gru_bwd: null argument");
   if (!aligned16(dy) || !aligned16(y) || !aligned16(saved) || !aligned16(w_hh) || !aligned16(dgi) || !aligned16(dgh)) return fail(AGNN_EALIGN, "gru_bwd: pointers must be 16-byte aligned");
-  if (hidden == 128)
-    hipLaunchKernelGGL(k_gru_bwd<128>, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), dy, y, saved, w_hh,
-                       static_cast<int>(T), dgi, dgh, drop_scale ? drop_scale : y, drop_scale ? 1.f : 0.f, hprev);
-  else
-    hipLaunchKernelGGL(k_gru_bwd<64>, dim3(static_cast<unsigned>(B * 2)), dim3(NT), 0, static_cast<hipStream_t>(stream_), dy, y, saved, w_hh,
-                       static_cast<int>(T), dgi, dgh, drop_scale ? drop_scale : y, drop_scale ? 1.f : 0.f, hprev);
+  const dim3 grid(static_cast<unsigned>(B * 2)), block(NT);
+  const hipStream_t st = static_cast<hipStream_t>(stream_);
+  const float* dr = drop_scale ? drop_scale : y;
+  const float use = drop_scale ? 1.f : 0.f;
+  const int Ti = static_cast<int>(T);
+  if (hidden == 128 && hprev) hipLaunchKernelGGL((k_gru_bwd<128, true>), grid, block, 0, st, dy, y, saved, w_hh, Ti, dgi, dgh, dr, use, hprev);
+  else if (hidden == 128) hipLaunchKernelGGL((k_gru_bwd<128, false>), grid, block, 0, st, dy, y, saved, w_hh, Ti, dgi, dgh, dr, use, hprev);
+  else if (hprev) hipLaunchKernelGGL((k_gru_bwd<64, true>), grid, block, 0, st, dy, y, saved, w_hh, Ti, dgi, dgh, dr, use, hprev);
+  else hipLaunchKernelGGL((k_gru_bwd<64, false>), grid, block, 0, st, dy, y, saved, w_hh, Ti, dgi, dgh, dr, use, hprev);
   return check_launch("gru_bwd");
 }

@@ -296,15 +296,16 @@ class _FlushPoint(torch.autograd.Function):
     on this stream so far (linear.defer_weight_grads) right there."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, side=None):
+        ctx.side = side
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
         _lib.stamp("flush (main) start", g.device)
-        flush_deferred()
+        flush_deferred(spill_to=ctx.side)
         _lib.stamp("flush (main) end", g.device)
-        return g
+        return g, None
 
 
 class _ForkInput(torch.autograd.Function):
@@ -437,7 +438,7 @@ class _HybridMixin:
             # deferred weight gradients: the two branches hang off one node whose backward is their join (_ForkInput), and the
             # GNN stack's input passes through the main stream's flush point (_FlushPoint)
             x_gnn, x_seq = _ForkInput.apply(x_in, batch_size, side)
-            gnn_note = _FlushPoint.apply(x_gnn)
+            gnn_note = _FlushPoint.apply(x_gnn, side)
         side.wait_stream(main)
         # x_in was allocated on the main stream and is READ on the side stream — in forward, and again in backward by the
         # first recurrent layer's weight gradient (its saved input is a view of x_in).  Without this the allocator hands the

@@ -205,6 +205,7 @@ def defer_home(fn, dev, tensors=()) -> bool:
         for t in tensors:
             if t is not None:
                 t.record_stream(here)
+    run.handed_over = True               # (flush_deferred's spill must not send it back to the stream it waits for)
     defer_on(home, run)
     return True
 
@@ -232,12 +233,60 @@ def _run_deferred(fns) -> None:
                 fn()
 
 
-def flush_deferred(dev=None) -> None:
-    """Run, on the current stream, the closures that were deferred on it."""
+FLUSH_KEEP = 1.0         # A/B switch (bench.py --flush-keep): share (by FLOPs) of a flush point's products that run there
+
+
+def _spill(fns, keep: float, other) -> list:
+    """Hand the LAST weight-gradient products of the list — each with the closures that follow it: its consumers — to `other`'s
+    flush until only `keep` of the list's FLOPs remain; returns what stays.  The operands are complete on the current stream now:
+    an event recorded here orders `other` behind them.  Work that was itself handed over from another stream (`event` set, or a
+    `defer_home` wrapper) stays where it was sent: `other` may be the stream it waits for."""
+    cost = lambda f: 2.0 * f.dy.shape[0] * f.dy.shape[1] * f.x.shape[1]                 # noqa: E731
+    units, cur = [], []                  # [leading closures], [product, its closures ...], ...
+    for f in fns:
+        if isinstance(f, WgItem):
+            units.append(cur)
+            cur = [f]
+        else:
+            cur.append(f)
+    units.append(cur)
+    movable = lambda u: (u and isinstance(u[0], WgItem) and u[0].event is None                                  # noqa: E731
+                         and not any(getattr(f, "event", None) is not None or getattr(f, "handed_over", False) for f in u[1:]))
+    total = sum(cost(u[0]) for u in units if u and isinstance(u[0], WgItem))
+    if total <= 0:
+        return fns
+    moved, out = 0.0, set()
+    for i in range(len(units) - 1, 0, -1):
+        u = units[i]
+        if not movable(u):
+            continue
+        if moved + cost(u[0]) > (1.0 - keep) * total + 1e-9:
+            break
+        moved += cost(u[0])
+        out.add(i)
+    if not out:
+        return fns
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(other.device))
+    for i in sorted(out):
+        for f in units[i]:
+            if isinstance(f, (WgItem, ColsumItem)):
+                f.event = ev
+            defer_on(other, f)
+    return [f for i, u in enumerate(units) if i not in out for f in u]
+
+
+def flush_deferred(dev=None, spill_to=None) -> None:
+    """Run, on the current stream, the closures that were deferred on it.  `spill_to`: another stream whose own flush comes
+    later and has room (the sequence branch's, which idles once the recurrence is through): with FLUSH_KEEP < 1 the last
+    products of the list go there."""
     s = torch.cuda.current_stream(dev)
     entry = _DEFER["pending"].pop((s.device.index, s.cuda_stream), None)
     if entry is not None:
-        _run_deferred(entry[1])
+        fns = entry[1]
+        if spill_to is not None and FLUSH_KEEP < 1.0:
+            fns = _spill(fns, FLUSH_KEEP, spill_to)
+        _run_deferred(fns)
         join_later(s)                    # whoever gathers the gradients waits for this stream (a no-op for its own)
 
 

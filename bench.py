@@ -82,6 +82,8 @@ def parse_args(argv=None):
     ap.add_argument("--items-home", default="auto", choices=["auto", "on", "off"],
                     help="a branch stream's deferred weight-gradient products: with the main chain's flush (on) / on the branch's own (off) / measured (auto)")
     ap.add_argument("--fused-heads", action="store_true", help="A/B only: the head block's forward in one launch (agnn_heads_fwd_f32)")
+    ap.add_argument("--flush-keep", type=float, default=None,
+                    help="share of the main flush point's weight-gradient FLOPs that runs there (rest: the sequence branch's flush); default: measured")
     ap.add_argument("--side-priority", type=int, default=0, help="A/B only: HIP priority of the sequence branch's stream (-1 = high)")
     ap.add_argument("--wgrad-scope", default="sequence", help="A/B only: kinds of weight-gradient work on the side stream")
     ap.add_argument("--library-wgrad", action="store_true", help="A/B only: weight gradients through the library GEMM")
@@ -350,6 +352,8 @@ def main():
     if args.fused_heads:
         from analysisgnn_amd import heads as _heads
         _heads.HEADS_FUSED = True
+    if args.flush_keep is not None:
+        _lin.FLUSH_KEEP = args.flush_keep
     if args.items_home != "auto":
         _lin.ITEMS_HOME = args.items_home == "on"
     opt = dp.FlatAdamW(params, flat, lr=5e-3, weight_decay=5e-3)     # analysis.py:1380-1381 hyper-parameters
@@ -426,10 +430,13 @@ def main():
             hybrid = enc in ("hybridgnn", "hgt") and not args.no_defer and not dot
             lates = [True, False] if args.schedule == "auto" and hybrid else [{"late": True, "plain": False, "auto": _enc.LATE_SEQUENCE_BACKWARD}[args.schedule]]
             homes = [True, False] if args.items_home == "auto" and hybrid else [_lin.ITEMS_HOME]
-            variants = [(a, b) for a in lates for b in homes]
+            # ... and for how much of the main flush point's weight-gradient work runs there: since the recurrence kernels got
+            # shorter (round 3) the main chain's flush outlasts the sequence branch, whose stream then has room for the rest
+            keeps = [1.0, 0.75, 0.5] if args.flush_keep is None and hybrid else [_lin.FLUSH_KEEP]
+            variants = [(a, b, k) for a in lates for b in homes for k in keeps]
             best = None
-            for late, home in variants:
-                _enc.LATE_SEQUENCE_BACKWARD, _lin.ITEMS_HOME = late, home
+            for late, home, keep in variants:
+                _enc.LATE_SEQUENCE_BACKWARD, _lin.ITEMS_HOME, _lin.FLUSH_KEEP = late, home, keep
                 g1 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g1, capture_error_mode=cap_mode):
                     loss_v = fwd_bwd()
@@ -451,17 +458,19 @@ def main():
                     dp.barrier_and_sync()
                     t_v = dp.max_over_ranks(time.perf_counter() - t0)
                 if best is None or t_v < best[0]:
-                    best = (t_v, g1, loss_v, late, gt, home)
-            _, g1, loss_ref[0], schedule_late, g_tail, schedule_home = best
-            _enc.LATE_SEQUENCE_BACKWARD, _lin.ITEMS_HOME = schedule_late, schedule_home
+                    best = (t_v, g1, loss_v, late, gt, home, keep)
+            _, g1, loss_ref[0], schedule_late, g_tail, schedule_home, schedule_keep = best
+            _enc.LATE_SEQUENCE_BACKWARD, _lin.ITEMS_HOME, _lin.FLUSH_KEEP = schedule_late, schedule_home, schedule_keep
             if rank == 0 and len(variants) > 1:
                 print(f"[bench] backward schedule: sequence branch {'behind a late node' if schedule_late else 'in autograd order'}, "
-                      f"its deferred products {'with the main flush' if schedule_home else 'on its own flush'}", file=sys.stderr)
+                      f"its deferred products {'with the main flush' if schedule_home else 'on its own flush'}, "
+                      f"{schedule_keep:g} of the main flush's products there", file=sys.stderr)
             with torch.cuda.graph(g2, capture_error_mode=cap_mode):
                 update()
             graphs = (g1, g2, g_tail)
             graph_mode = (f"hipGraph replay (capture_error_mode={cap_mode}; sequence branch {'late node' if schedule_late else 'autograd order'}, "
-                          f"its deferred products {'in the main flush' if schedule_home else 'in its own flush'})")
+                          f"its deferred products {'in the main flush' if schedule_home else 'in its own flush'}, "
+                          f"{schedule_keep:g} of the main flush's weight-gradient FLOPs there)")
         except Exception as e:                                  # capture refused: run eagerly — a HOST-BOUND number, flagged at top level
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graphs = None

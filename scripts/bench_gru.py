@@ -42,3 +42,10 @@ f = timed(lambda: _lib.check(lib.agnn_gru_fwd_f32(gi.data_ptr(), w.data_ptr(), b
 dyv = torch.randn_like(yy)
 bw = timed(lambda: _lib.check(lib.agnn_gru_bwd_f32(dyv.data_ptr(), yy.data_ptr(), saved.data_ptr(), w.data_ptr(), B, T, Hh, dgi.data_ptr(), dgh.data_ptr(), None, None, st), "bwd"))
 print(f"B={B} T={T}: k_gru_fwd {f:.1f} us = {f / T:.3f} us/step ({f / T * 2400:.0f} cycles @2.4 GHz); k_gru_bwd {bw:.1f} us = {bw / T:.3f} us/step")
+hp = torch.empty(B, T, 2, Hh, device=dev)
+drop = torch.ones(B, T, 2 * Hh, device=dev)
+y2 = torch.empty_like(yy)
+f2 = timed(lambda: _lib.check(lib.agnn_gru_fwd_f32(gi.data_ptr(), w.data_ptr(), bh.data_ptr(), B, T, Hh, yy.data_ptr(), saved.data_ptr(), drop.data_ptr(), y2.data_ptr(), st), "fwd"))
+b2 = timed(lambda: _lib.check(lib.agnn_gru_bwd_f32(dyv.data_ptr(), yy.data_ptr(), saved.data_ptr(), w.data_ptr(), B, T, Hh, dgi.data_ptr(), dgh.data_ptr(), None, hp.data_ptr(), st), "bwd"))
+b3 = timed(lambda: _lib.check(lib.agnn_gru_bwd_f32(dyv.data_ptr(), yy.data_ptr(), saved.data_ptr(), w.data_ptr(), B, T, Hh, dgi.data_ptr(), dgh.data_ptr(), drop.data_ptr(), hp.data_ptr(), st), "bwd"))
+print(f"as in the training step: k_gru_fwd with dropout scale {f2:.1f} us; k_gru_bwd with hprev output {b2:.1f} us, + dropout scale {b3:.1f} us")
