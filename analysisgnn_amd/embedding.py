@@ -110,4 +110,8 @@ def embed_cat(x: torch.Tensor, idxs: Sequence[torch.Tensor], tables: Sequence[to
             and tables[0].shape[1] % 2 == 0 and all(i.dim() == 1 and i.shape[0] == x.shape[0] for i in idxs))
     if not fits:
         return torch.cat([x] + [embedding(i, t) for i, t in zip(idxs, tables)], dim=-1)
-    return _EmbedCat.apply(x, n_tab, *idxs, *tables)
+    r = _EmbedCat.apply(x, n_tab, *idxs, *tables)
+    # x gets no gradient: whoever consumes r only owes the gradient of the embedding columns (linear._LinearFn computes dX for
+    # these columns alone: a [N, 256] x [256, 128] product instead of x [256, 281])
+    r._agnn_grad_cols = (int(x.shape[1]), int(r.shape[1]))
+    return r

@@ -346,7 +346,7 @@ class _ForkInput(torch.autograd.Function):
             out = torch.empty_like(g)
             torch.add(g[:ctx.n], g_seq, out=out[:ctx.n])
             if ctx.n < g.shape[0]:
-                out[ctx.n:].copy_(g[ctx.n:])
+                torch.mul(g[ctx.n:], 1.0, out=out[ctx.n:])       # (an element-wise launch: the runtime's copy kernel took 11 us for 335 rows)
             g = out
         return g, None, None
 

@@ -463,6 +463,7 @@ class _LinearFn(torch.autograd.Function):
         ctx.wg_async = _async_ok(w) and _async_ok(b)
         ctx.wg_defer = _deferrable(w) and _deferrable(b)
         ctx.steal_refs = leaf_refs(w, b)
+        ctx.grad_cols = getattr(x, "_agnn_grad_cols", None) if x.dim() == 2 else None     # (embedding.embed_cat: only these columns of dX are read)
         ctx.set_materialize_grads(False)          # an undefined output gradient (a structurally dead branch) stays undefined upstream
         if pre is not None:
             return pre[0]
@@ -498,7 +499,18 @@ class _LinearFn(torch.autograd.Function):
             # forked before dX is queued: both start at once — only when the gradients will be STOLEN (no kernel on the main stream)
             with wgrad_stream(dy.device, dy, x, active=steals):
                 dw, db = weight_grad(dy, x, want_b)
-        dx = dy @ w if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            gc = ctx.grad_cols
+            if gc is not None and x.stride(1) == 1 and x.stride(0) >= x.shape[1] and w.stride(1) == 1 and dy.is_cuda:
+                # the producer only reads columns [c0, c1) of dX (the other inputs are data): the product over those columns of W,
+                # written in place into a matrix with the producer's row stride; the rest of it stays unwritten
+                c0, c1 = gc
+                full = torch.empty((dy.shape[0], x.stride(0)), dtype=dy.dtype, device=dy.device)
+                torch.mm(dy, w[:, c0:c1], out=full[:, c0:c1])
+                dx = full[:, :x.shape[1]]
+            else:
+                dx = dy @ w
         return dx, dw, db, (dy if ctx.needs_input_grad[3] else None), None
 
 
