@@ -206,6 +206,9 @@ class HeteroSAGEStack(nn.Module):
         for i, conv in enumerate(self.convs):
             keep = n_out[i]
             x_dict = {k: v for k, v in x_dict.items()}
+            if i == 1:
+                from .gru import wait_for_projections
+                wait_for_projections(x_dict["note"].device)      # the sequence branch's inner input projection gets the chip to itself
             x_dict = conv(x_dict, edge_index_dict, index, keep, plan.e_keep[i])
             if i < self.num_layers - 1:
                 x_dict = {k: norm_act(v, self.layer_norms[i], post_relu=True, p=self.dropout, training=self.training)

@@ -17,6 +17,19 @@ from .linear import (WgItem, all_steal, defer, defer_home, deferring, leaf_refs,
 KERNEL_HIDDEN = (64, 128)      # hidden sizes per direction the kernels are instantiated for (H = 128 / 256 hybrid models)
 
 
+YIELD_TO_PROJECTIONS = True      # A/B switch (bench.py --no-yield-gemm)
+PROJECTION_EVENTS: list = []
+
+
+def wait_for_projections(device) -> None:
+    """Called by the graph stacks before their second layer: the current stream waits for the sequence branch's inner input
+    projections issued so far (a no-op when there is no sequence branch, or it runs on this very stream)."""
+    while PROJECTION_EVENTS:
+        ev = PROJECTION_EVENTS.pop()
+        if torch.device(device).type == "cuda":
+            torch.cuda.current_stream(device).wait_event(ev)
+
+
 class _GRULayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, last_in_backward=False, drop_scale=None):
@@ -31,6 +44,16 @@ class _GRULayer(torch.autograd.Function):
         x2 = x.reshape(B * T, I)
         # 1-D bias: the library adds it in the GEMM epilogue (a [1, 6H] operand is first broadcast-copied into the 49 MB result)
         gi = torch.addmm(b_ih.reshape(-1), x2, w_ih.reshape(6 * Hh, I).t())         # [B*T, 2*3H]
+        if last_in_backward:
+            PROJECTION_EVENTS.clear()            # first layer of a new sequence pass: nobody collected the previous pass's events
+        elif YIELD_TO_PROJECTIONS:
+            # an inner layer's input projection sits between two recurrence kernels on the step's longest chain: whoever runs
+            # GEMMs beside it (the GNN stack on the main stream, which has ~0.2 ms of slack) waits for this event instead of
+            # halving its speed (wait_for_projections; C2 step 3.153 -> 3.104 ms).  The same on the way back — the main chain's
+            # weight-gradient flush waiting for the inner dX projection — cost 0.09 ms and is not done.
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            PROJECTION_EVENTS.append(ev)
         w_hh_c = w_hh.contiguous()
         b_hh_c = b_hh.contiguous()
         y = torch.empty((B, T, 2 * Hh), dtype=torch.float32, device=dev)

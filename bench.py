@@ -84,6 +84,7 @@ def parse_args(argv=None):
     ap.add_argument("--fused-heads", action="store_true", help="A/B only: the head block's forward in one launch (agnn_heads_fwd_f32)")
     ap.add_argument("--flush-keep", type=float, default=None,
                     help="share of the main flush point's weight-gradient FLOPs that runs there (rest: the sequence branch's flush); default: measured")
+    ap.add_argument("--no-yield-gemm", action="store_true", help="A/B only: the graph stack's second layer does not wait for the GRU's inner input projection")
     ap.add_argument("--side-priority", type=int, default=0, help="A/B only: HIP priority of the sequence branch's stream (-1 = high)")
     ap.add_argument("--wgrad-scope", default="sequence", help="A/B only: kinds of weight-gradient work on the side stream")
     ap.add_argument("--library-wgrad", action="store_true", help="A/B only: weight gradients through the library GEMM")
@@ -352,6 +353,9 @@ def main():
     if args.fused_heads:
         from analysisgnn_amd import heads as _heads
         _heads.HEADS_FUSED = True
+    if args.no_yield_gemm:
+        from analysisgnn_amd import gru as _gru
+        _gru.YIELD_TO_PROJECTIONS = False
     if args.flush_keep is not None:
         _lin.FLUSH_KEEP = args.flush_keep
     if args.items_home != "auto":
