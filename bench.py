@@ -85,6 +85,8 @@ def parse_args(argv=None):
     ap.add_argument("--flush-keep", type=float, default=None,
                     help="share of the main flush point's weight-gradient FLOPs that runs there (rest: the sequence branch's flush); default: measured")
     ap.add_argument("--no-yield-gemm", action="store_true", help="A/B only: the graph stack's second layer does not wait for the GRU's inner input projection")
+    ap.add_argument("--no-tune-gemm", action="store_true",
+                    help="library GEMMs as hipBLASLt's heuristic picks them (default: PyTorch TunableOp times the candidates during the eager warm-up steps)")
     ap.add_argument("--side-priority", type=int, default=0, help="A/B only: HIP priority of the sequence branch's stream (-1 = high)")
     ap.add_argument("--wgrad-scope", default="sequence", help="A/B only: kinds of weight-gradient work on the side stream")
     ap.add_argument("--library-wgrad", action="store_true", help="A/B only: weight gradients through the library GEMM")
@@ -414,6 +416,27 @@ def main():
     # error mode any such call from another thread invalidates a capture in progress.  thread_local confines the check to the
     # capturing thread (what torch's own DDP + CUDA-graph recipes use).  One-rank runs keep the stricter default.
     cap_mode = "thread_local" if (world > 1 or torch.distributed.is_initialized()) else "global"
+    # The forward / input-gradient projections are library GEMMs.  hipBLASLt's heuristic pick for these tall shapes is not its
+    # fastest kernel (round 2: 66 vs 119 us for [16000, 1024] x [1024, 256]); PyTorch's TunableOp times the candidates the first
+    # time a shape is seen — here during the eager warm-up steps — and is frozen before the step is captured.  C2 3.08 -> 3.02 ms,
+    # C5 6.33 -> 6.20 (round 3; in round 2 the tuned kernels shared the chip worse with the recurrence kernels, which now keep
+    # their CUs to themselves).  A library setting any user of the package can make; `--no-tune-gemm` measures without it.
+    gemm_selection = "hipBLASLt heuristic"
+    if not args.no_tune_gemm:
+        try:
+            import tempfile
+            _tn = torch.cuda.tunable
+            _tn.set_filename(os.path.join(tempfile.gettempdir(), f"agnn_tunableop_{args.workload}_r{rank}.csv"))
+            _tn.enable(True)
+            _tn.tuning_enable(True)
+            gemm_selection = "hipBLASLt via PyTorch TunableOp (candidates timed during the eager warm-up steps, frozen before capture)"
+        except Exception as e:                                   # an older torch: measured as the heuristic picks
+            print(f"[bench] TunableOp unavailable ({type(e).__name__}: {e})", file=sys.stderr)
+
+    def _freeze_gemm_selection():
+        if gemm_selection.startswith("hipBLASLt via"):
+            torch.cuda.tunable.tuning_enable(False)              # keep what was found; never tune inside a capture
+
     if not args.no_graph:
         try:
             side = torch.cuda.Stream(device=dev)
@@ -422,6 +445,8 @@ def main():
                 for _ in range(3):
                     fwd_bwd(); reduce_between(bwd_tail); update()
             torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            _freeze_gemm_selection()
             dp.barrier_and_sync()                               # no collective in flight on any rank while capturing
             g2 = torch.cuda.CUDAGraph()
             dot = args.graph_dot                                 # the captured step's dependency graph as DOT (debugging)
@@ -543,6 +568,7 @@ def main():
             # how the step's launches were issued: "hipGraph replay ..." or "eager-fallback: <why the capture failed>" (then the
             # figure is bound by the host's launch rate, not by the GPU — do not read it as the step's speed)
             "graph": graph_mode,
+            "gemm_selection": gemm_selection,
             "config": {"workload": WORKLOADS[args.workload] + f"; {g.num_nodes['note']} notes, {e_tot} edges per GPU; train step = fwd + "
                                    f"objective ({args.mt_strategy}) + bwd + allreduce + clip + AdamW, CSR rebuilt every step; "
                                    + ("hipGraph replay" if graphs is not None else "EAGER launches (see \"graph\")"),
@@ -568,16 +594,20 @@ def main():
             # nothing trimmed); "c2d" = the same training step with the batch sampled and gathered ON THE DEVICE inside it
             out["other_workloads"] = {}
             for wl in ("c2", "c2d", "c3", "c3d", "c5"):
+                r = None
                 try:
-                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", wl, "--no-cpu-baseline", "--steps",
-                                        str(args.steps), "--warmup", str(args.warmup), "--mt-strategy", args.mt_strategy],
-                                       capture_output=True, text=True, timeout=300)
+                    cmd = [sys.executable, "-X", "faulthandler", os.path.abspath(__file__), "--workload", wl, "--no-cpu-baseline", "--steps",
+                           str(args.steps), "--warmup", str(args.warmup), "--mt-strategy", args.mt_strategy]
+                    if args.no_tune_gemm:
+                        cmd.append("--no-tune-gemm")
+                    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
                     o = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
                     out["other_workloads"][wl] = {"metric": o["metric"], "value": o["value"], "ms_per_step": o["ms_per_step"],
                                                   "workload": o["config"]["workload"], "graph": o["graph"], "roofline": o["roofline"],
                                                   "step_flops_alg": o["step_flops_alg"], "mfma_frac": o["mfma_frac"]}
-                except Exception as e:                              # secondary figures only
-                    out["other_workloads"][wl] = f"not measured ({type(e).__name__})"
+                except Exception as e:                              # secondary figures only; say why (the child's last lines)
+                    why = " | ".join((r.stderr or "").strip().splitlines()[-6:]) if r is not None else ""
+                    out["other_workloads"][wl] = f"not measured ({type(e).__name__}; exit code {getattr(r, 'returncode', None)}; {why[-600:]})"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.mt_strategy)
         print(json.dumps(out))
