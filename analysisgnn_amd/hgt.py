@@ -17,7 +17,7 @@ from . import _lib
 from .encoders import TrimPlan, _HybridMixin
 from .graph import Csr, HeteroIndex, hetero_index
 from .fused import skip_act
-from .linear import linear
+from .linear import all_steal, defer, deferring, leaf_refs, linear
 from .params import cat_rows, pack
 
 EdgeType = Tuple[str, str, str]
@@ -366,6 +366,8 @@ class _HGTCore(torch.autograd.Function):
             stats[t] = (m, linv)
             outs.append(out)
         ctx.plan = plan
+        ctx.steal_refs = leaf_refs(wk, wv)             # (their gradients may be produced late: see backward)
+        ctx.wg_defer = all(t.is_leaf or getattr(t, "_agnn_wgrad_deferrable", False) for t in (wk, wv))
         ctx.srcs = list(plan.src_rels.keys())
         ctx.dsts = list(stats.keys())
         saved = list(X.values()) + [ps]
@@ -467,6 +469,7 @@ class _HGTCore(torch.autograd.Function):
                 written.add(e_idx)
         gwk = gwv = None
         wk_shape, wv_shape, p_shape = ctx.shapes
+        later = ctx.wg_defer and dev.type == "cuda" and deferring(next(iter(X.values()))) and all_steal(ctx.steal_refs)
         dead = set()                                                 # types whose whole d kqv is structurally zero: hand back None,
         for s_t in plan.types:                                       # so that autograd prunes everything upstream of it
             x = X[s_t]
@@ -494,23 +497,36 @@ class _HGTCore(torch.autograd.Function):
                 for it, (dy, w, off) in zip(items, ((dkp[s_t], Wkt, 0), (dvp[s_t], Wvt, 2 * H))):
                     it.x, it.w, it.y, it.ld_x, it.ld_y = dy.data_ptr(), w.data_ptr(), dx.data_ptr() + 4 * off, dy.stride(0), dx.stride(0)
                 _lib.check(lib.agnn_relt_bwd_f32(2, items, R, heads, D, N, st), "agnn_relt_bwd_f32")
+            # The relation weights' gradients only feed the optimizer: with dp.defer_weight_grads they leave the stack's backward
+            # chain (95 us per layer at C3, between the input-gradient transform and the next layer's backward) and run at the
+            # stream's flush.  The closure works on aliases (a second reference to the returned gradient would make
+            # AccumulateGrad clone it before it is computed: see linear._LinearFn.backward).
             dWk, dWv = torch.empty_like(Wk[s_t]), torch.empty_like(Wv[s_t])
-            nws = int(lib.agnn_relt_dw_workspace_bytes(2, R, heads, D, N))
-            ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=dev)
-            items = (_lib.ReltItem * 2)()
-            for it, (off, dy, y) in zip(items, ((0, dkp[s_t], dWk), (2 * H, dvp[s_t], dWv))):
-                it.x, it.w, it.y, it.ld_x, it.ld_y = x.data_ptr() + 4 * off, dy.data_ptr(), y.data_ptr(), x.stride(0), dy.stride(0)
-            _lib.check(lib.agnn_relt_dw_f32(2, items, R, heads, D, N, ws.data_ptr(), nws, st), "agnn_relt_dw_f32")
             ids = tuple(e * heads + h for e in e_ids for h in range(heads))
-            if gwk is None and ids == tuple(range(wk_shape[0])) and len(ctx.srcs) == 1:
+            whole = gwk is None and ids == tuple(range(wk_shape[0])) and len(ctx.srcs) == 1
+            if whole:
                 gwk, gwv = dWk, dWv                                  # the one source type covers the whole parameter
-                continue
-            if gwk is None:
+            elif gwk is None:
                 gwk = torch.zeros(wk_shape, dtype=torch.float32, device=dev)
                 gwv = torch.zeros(wv_shape, dtype=torch.float32, device=dev)
-            sel = _index_tensor(ids, dev)
-            gwk.index_copy_(0, sel, dWk)
-            gwv.index_copy_(0, sel, dWv)
+
+            def weight_grads(x=x, dk_=dkp[s_t], dv_=dvp[s_t], dWk=dWk.detach(), dWv=dWv.detach(), R=R, N=N, ids=ids, whole=whole,
+                             gk=gwk.detach(), gv=gwv.detach()):
+                nws = int(lib.agnn_relt_dw_workspace_bytes(2, R, heads, D, N))
+                ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=dev)
+                items = (_lib.ReltItem * 2)()
+                for it, (off, dy, y) in zip(items, ((0, dk_, dWk), (2 * H, dv_, dWv))):
+                    it.x, it.w, it.y, it.ld_x, it.ld_y = x.data_ptr() + 4 * off, dy.data_ptr(), y.data_ptr(), x.stride(0), dy.stride(0)
+                _lib.check(lib.agnn_relt_dw_f32(2, items, R, heads, D, N, ws.data_ptr(), nws, _lib.stream_ptr(dev)), "agnn_relt_dw_f32")
+                if not whole:
+                    sel = _index_tensor(ids, dev)
+                    gk.index_copy_(0, sel, dWk)
+                    gv.index_copy_(0, sel, dWv)
+
+            if later:
+                defer(weight_grads, dev)
+            else:
+                weight_grads()
         if dps_rows and tuple(dps_ids) == tuple(range(p_shape[0])):
             dp_all = (torch.cat(dps_rows, dim=0) * (1.0 / math.sqrt(D))).view(p_shape)
         else:
