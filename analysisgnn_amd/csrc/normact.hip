@@ -147,6 +147,10 @@ __global__ __launch_bounds__(256) void k_na_bwd(NaArgs a, const float* __restric
                                                 const float* __restrict__ rstd_in, float* __restrict__ dx, int64_t ld_dx,
                                                 float* __restrict__ part) {
   const int lane = threadIdx.x & 63;
+  // blockIdx.y: a column block of CH * 256 floats (segmented statistics only: the segments of a row are independent, so a wide
+  // row — the task heads' [N, 21 * 64] — is split over 6 light waves with 8 per SIMD instead of one 254-register wave with 2:
+  // 68 -> 4x us at C2; a whole-row LayerNorm always has blockIdx.y = 0)
+  const int cb = blockIdx.y * 256 * CH;
   const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int n_waves = gridDim.x * 4;
   const bool pre = a.flags & AGNN_NA_PRE_RELU, post = a.flags & AGNN_NA_POST_RELU, drop = a.p > 0.f;
@@ -159,21 +163,21 @@ __global__ __launch_bounds__(256) void k_na_bwd(NaArgs a, const float* __restric
   const float invS = 1.f / static_cast<float>(whole ? a.H : a.seg);
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
-    on[c] = (c * 256 + lane * 4) < a.H;
-    gm[c] = on[c] ? reinterpret_cast<const float4*>(a.gamma)[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-    bt[c] = on[c] ? reinterpret_cast<const float4*>(a.beta)[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    on[c] = (cb + c * 256 + lane * 4) < a.H;
+    gm[c] = on[c] ? reinterpret_cast<const float4*>(a.gamma + cb)[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    bt[c] = on[c] ? reinterpret_cast<const float4*>(a.beta + cb)[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
     dg[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     db[c] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   for (int64_t row = wave_g; row < a.n; row += n_waves) {
-    const float4* xp = reinterpret_cast<const float4*>(a.x + row * a.ld_x);
-    const float4* gp = reinterpret_cast<const float4*>(dy + row * ld_dy);
+    const float4* xp = reinterpret_cast<const float4*>(a.x + row * a.ld_x + cb);
+    const float4* gp = reinterpret_cast<const float4*>(dy + row * ld_dy + cb);
     float4 xr[CH], xh[CH], gx[CH];
     float rs[CH], p1[CH], p2[CH];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      const int sidx = whole ? 0 : (on[c] ? (c * 256 + lane * 4) / a.seg : 0);
+      const int sidx = whole ? 0 : (on[c] ? (cb + c * 256 + lane * 4) / a.seg : 0);
       const float mean = mean_in[row * nseg + sidx], rstd = rstd_in[row * nseg + sidx];
       rs[c] = rstd;
       xr[c] = on[c] ? xp[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256) void k_na_bwd(NaArgs a, const float* __restric
       xh[c] = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
       if (!on[c]) xh[c] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (drop) {
-        const float4 m = keep_mask(a, row, c * 64 + lane, scale);
+        const float4 m = keep_mask(a, row, cb / 4 + c * 64 + lane, scale);
         g.x *= m.x; g.y *= m.y; g.z *= m.z; g.w *= m.w;
       }
       if (post) {
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(256) void k_na_bwd(NaArgs a, const float* __restric
 #pragma unroll
       for (int c = 0; c < CH; ++c) { m1[c] = gsum(p1[c], gl) * invS; m2[c] = gsum(p2[c], gl) * invS; }
     }
-    float4* op = reinterpret_cast<float4*>(dx + row * ld_dx);
+    float4* op = reinterpret_cast<float4*>(dx + row * ld_dx + cb);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       if (!on[c]) continue;
@@ -244,8 +248,8 @@ __global__ __launch_bounds__(256) void k_na_bwd(NaArgs a, const float* __restric
     __syncthreads();
   }
   if (wave == 0) {
-    float4* pg = reinterpret_cast<float4*>(part + static_cast<int64_t>(blockIdx.x) * 2 * a.H);
-    float4* pb = reinterpret_cast<float4*>(part + static_cast<int64_t>(blockIdx.x) * 2 * a.H + a.H);
+    float4* pg = reinterpret_cast<float4*>(part + static_cast<int64_t>(blockIdx.x) * 2 * a.H + cb);
+    float4* pb = reinterpret_cast<float4*>(part + static_cast<int64_t>(blockIdx.x) * 2 * a.H + a.H + cb);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       if (!on[c]) continue;
@@ -493,8 +497,14 @@ extern "C" int agnn_norm_act_bwd_f32(const float* x, int64_t ld_x, const float* 
   hipStream_t s = static_cast<hipStream_t>(stream_);
   int nb = static_cast<int>((n + 3) / 4);                 // at least one row per wave
   if (nb > kBwdBlocks) nb = kBwdBlocks;
-  const dim3 grid(nb), block(256);
-  AGNN_NA_DISPATCH(k_na_bwd, a, dy, ld_dy, mean, rstd, dx, ld_dx, part);
+  const dim3 block(256);
+  if (seg < H && H > 256) {                               // segmented statistics: one light wave per 256-column block of a row
+    const dim3 grid(nb, static_cast<unsigned>((H + 255) / 256));
+    hipLaunchKernelGGL(k_na_bwd<1>, grid, block, 0, s, a, dy, ld_dy, mean, rstd, dx, ld_dx, part);
+  } else {
+    const dim3 grid(nb);
+    AGNN_NA_DISPATCH(k_na_bwd, a, dy, ld_dy, mean, rstd, dx, ld_dx, part);
+  }
   if (int rc = check_launch("norm_act_bwd")) return rc;
   if (dgamma == nullptr) return AGNN_OK;              // the column sums are launched later: agnn_norm_act_colsum_f32
   const int width = 2 * H;
