@@ -1,4 +1,5 @@
-// Batched small 2-D gather/sum:  dst_i[r, c] = sum_{k < n_src_i} src_{i,k}[r, c]   for up to AGNN_PACK_MAX_ITEMS items per launch.
+// Batched small 2-D gather/sum:  dst_i[r, c] = sum_{k < n_src_i} src_{i,k}[r, c]   for up to AGNN_PACK_MAX_ITEMS items per launch
+// (n_src_i = 0: the piece is zero-filled — the HGT backward's column-block clears, one launch instead of one per block).
 //
 // The fused layers present per-relation / per-task parameters to the GEMMs as ONE operand (PyG HeteroConv's four
 // SAGEConv.lin_l weights side by side, their lin_r weights and biases summed — ref: models/cadence.py:147-159,174) and
@@ -32,7 +33,8 @@ __global__ __launch_bounds__(256) void k_pack(PackTable t) {
       if (e >= (total >> 2)) break;
       const int64_t r = e / c4;
       const int c = static_cast<int>(e - r * c4) * 4;
-      float4 s = *reinterpret_cast<const float4*>(it.src[0] + r * it.ld_src + c);
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (it.n_src > 0) s = *reinterpret_cast<const float4*>(it.src[0] + r * it.ld_src + c);
       for (int k = 1; k < it.n_src; ++k) {
         const float4 v = *reinterpret_cast<const float4*>(it.src[k] + r * it.ld_src + c);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(256) void k_pack(PackTable t) {
       if (e >= total) break;
       const int64_t r = e / it.cols;
       const int c = static_cast<int>(e - r * it.cols);
-      float s = it.src[0][r * it.ld_src + c];
+      float s = it.n_src > 0 ? it.src[0][r * it.ld_src + c] : 0.f;
       for (int k = 1; k < it.n_src; ++k) s += it.src[k][r * it.ld_src + c];
       it.dst[r * it.ld_dst + c] = s;
     }
@@ -66,10 +68,11 @@ extern "C" int agnn_pack_f32(int32_t n_items, const agnn_pack_item_t* items, agn
     int32_t blocks = 0;
     for (int32_t i = at; i < n_items && t.n < AGNN_PACK_MAX_ITEMS; ++i) {
       agnn_pack_item_t it = items[i];
-      if (it.rows < 0 || it.cols < 0 || it.n_src < 1 || it.n_src > AGNN_PACK_MAX_SRC)
+      if (it.rows < 0 || it.cols < 0 || it.n_src < 0 || it.n_src > AGNN_PACK_MAX_SRC)
         return fail(AGNN_EINVAL, "pack: item %d has rows=%d cols=%d n_src=%d", i, it.rows, it.cols, it.n_src);
       if (it.rows == 0 || it.cols == 0) continue;
-      if (!it.dst || it.ld_dst < it.cols || it.ld_src < it.cols) return fail(AGNN_EINVAL, "pack: item %d: null dst or ld < cols", i);
+      if (!it.dst || it.ld_dst < it.cols || (it.n_src > 0 && it.ld_src < it.cols)) return fail(AGNN_EINVAL, "pack: item %d: null dst or ld < cols", i);
+      if (it.n_src == 0) it.ld_src = it.ld_dst;
       bool v = aligned16(it.dst) && (it.ld_dst & 3) == 0 && (it.ld_src & 3) == 0;
       for (int k = 0; k < it.n_src; ++k) {
         if (!it.src[k]) return fail(AGNN_EINVAL, "pack: item %d: null source %d", i, k);

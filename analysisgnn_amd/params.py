@@ -16,13 +16,13 @@ from .linear import all_steal, defer, deferring, mark_wgrad_async, wgrad_stream
 
 
 def pack(items: Sequence[Tuple[torch.Tensor, Sequence[torch.Tensor]]], device) -> None:
-    """items: (dst 2-D view, [src 2-D views of the same shape and row stride]);  dst = sum(srcs)."""
+    """items: (dst 2-D view, [src 2-D views of the same shape and row stride]);  dst = sum(srcs); no sources: dst = 0."""
     arr = (_lib.PackItem * len(items))()
     for i, (dst, srcs) in enumerate(items):
         if len(srcs) > _lib.PACK_MAX_SRC:
             raise _lib.AgnnError(f"pack: {len(srcs)} sources (max {_lib.PACK_MAX_SRC})")
         rows, cols = dst.shape
-        ld_src = srcs[0].stride(0) if rows > 1 else max(cols, 1)
+        ld_src = (srcs[0].stride(0) if rows > 1 else max(cols, 1)) if srcs else max(cols, 1)
         for t in (dst, *srcs):
             if t.dtype != torch.float32 or t.dim() != 2 or (cols > 1 and t.stride(1) != 1) or tuple(t.shape) != (rows, cols):
                 raise _lib.AgnnError("pack: fp32 2-D pieces of one shape with unit inner stride expected")

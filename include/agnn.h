@@ -392,6 +392,7 @@ int agnn_wgrad_batch_f32(int32_t n_items, const agnn_wgrad_item_t* items /* (hos
  * Used to present per-relation parameters as one GEMM operand (PyG HeteroConv over SAGEConv: the lin_l weights side by
  * side, lin_r weights and biases summed — ref: models/cadence.py:147-159,174) and to split / fan out the operand's
  * gradient again.  All sources of an item share ld_src.  Destinations of different items must not overlap.
+ * n_src_i = 0 zero-fills the piece (ld_src ignored).
  * `vec_ok` is filled in by the library.  Items are read on the host during the call.
  * ------------------------------------------------------------------------------------------ */
 #define AGNN_PACK_MAX_SRC   8
