@@ -51,6 +51,12 @@ class Rel(C.Structure):
                 ("ew", C.c_void_p), ("colscale", C.c_void_p), ("ld_src", C.c_int64)]
 
 
+class HgtSrcItem(C.Structure):
+    _fields_ = [("rowptr", C.c_void_p), ("rowend", C.c_void_p), ("col", C.c_void_p), ("perm", C.c_void_p), ("alpha", C.c_void_p),
+                ("gs", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p), ("ld_o", C.c_int64), ("n_src_rows", C.c_int32),
+                ("col_limit", C.c_int32)]
+
+
 class HgtRel(C.Structure):
     _fields_ = [("k", C.c_void_p), ("v", C.c_void_p), ("rowptr", C.c_void_p), ("rowend", C.c_void_p),
                 ("col", C.c_void_p), ("perm", C.c_void_p), ("pscale", C.c_void_p), ("ld", C.c_int64),
@@ -116,6 +122,8 @@ SIGNATURES = {
     "agnn_hgt_attn_bwd_src_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
                                             C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "agnn_hgt_attn_bwd_src_batch_f32": (C.c_int, [C.c_int32, C.POINTER(HgtSrcItem), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                                  C.c_int32, C.c_int32, C.c_void_p]),
     "agnn_sampler_num_nodes": (C.c_int64, [C.POINTER(Sampler)]),
     "agnn_sampler_edge_capacity": (C.c_int64, [C.POINTER(Sampler)]),
     "agnn_sample_hops": (C.c_int, [C.POINTER(Sampler), C.c_void_p]),

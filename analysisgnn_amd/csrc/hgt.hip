@@ -244,14 +244,14 @@ __global__ __launch_bounds__(256) void k_hgt_bwd_dst(HgtTable t, HgtArgs a, cons
 // Pass by source (one relation, transposed CSR: rows = source nodes, col = destination rows):
 //   dV'[j] = sum_e alpha_e dM[i(e)]   ;   dK'[j] = sum_e gs_e q[i(e)]     (per head)
 template <int CH>
-__global__ __launch_bounds__(256) void k_hgt_bwd_src(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend,
-                                                     const int32_t* __restrict__ col, const int32_t* __restrict__ perm,
-                                                     const float* __restrict__ alpha, const float* __restrict__ gs, HgtArgs a,
-                                                     const float* __restrict__ dm, int64_t ld_dm, float* __restrict__ dk,
-                                                     float* __restrict__ dv, int64_t ld_o) {
+__device__ __forceinline__ void hgt_bwd_src_rows(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend,
+                                                 const int32_t* __restrict__ col, const int32_t* __restrict__ perm,
+                                                 const float* __restrict__ alpha, const float* __restrict__ gs, const HgtArgs& a,
+                                                 const float* __restrict__ dm, int64_t ld_dm, float* __restrict__ dk,
+                                                 float* __restrict__ dv, int64_t ld_o, const int block, const int n_blocks) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int vb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int vb = (block & 7) * (n_blocks >> 3) + (block >> 3);
   const int row = vb * 4 + wave;
   if (row >= a.n_rows) return;
   const int D = a.H / a.heads;
@@ -304,6 +304,37 @@ __global__ __launch_bounds__(256) void k_hgt_bwd_src(const int32_t* __restrict__
     okp[c * 64 + lane] = dka[c];
     ovp[c * 64 + lane] = dva[c];
   }
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void k_hgt_bwd_src(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend,
+                                                     const int32_t* __restrict__ col, const int32_t* __restrict__ perm,
+                                                     const float* __restrict__ alpha, const float* __restrict__ gs, HgtArgs a,
+                                                     const float* __restrict__ dm, int64_t ld_dm, float* __restrict__ dk,
+                                                     float* __restrict__ dv, int64_t ld_o) {
+  hgt_bwd_src_rows<CH>(rowptr, rowend, col, perm, alpha, gs, a, dm, ld_dm, dk, dv, ld_o, blockIdx.x, gridDim.x);
+}
+
+// All relations that end in one destination type in ONE launch (they share q and dM; each writes its own column block of its
+// source type's dK' / dV'): as separate launches they were four ~13 us kernels in a row on the HGT stack's backward chain.
+struct SrcBatch {
+  agnn_hgt_src_item_t it[AGNN_MAX_SEG];
+  int32_t first[AGNN_MAX_SEG + 1];       // first workgroup of item i (each item's count is a multiple of 8: XCD-contiguous slabs)
+  const float* q;
+  const float* dm;
+  int64_t ld_q, ld_dm;
+  int32_t n, H, heads;
+};
+
+template <int CH>
+__global__ __launch_bounds__(256) void k_hgt_bwd_src_batch(SrcBatch b) {
+  int i = 0;
+  const int blk = blockIdx.x;
+  while (i + 1 < b.n && blk >= b.first[i + 1]) ++i;              // workgroup-uniform
+  const agnn_hgt_src_item_t& it = b.it[i];
+  const HgtArgs a{b.q, b.ld_q, it.n_src_rows, b.H, b.heads, it.col_limit};
+  hgt_bwd_src_rows<CH>(it.rowptr, it.rowend, it.col, it.perm, it.alpha, it.gs, a, b.dm, b.ld_dm, it.dk, it.dv, it.ld_o, blk - b.first[i],
+                       b.first[i + 1] - b.first[i]);
 }
 
 int check_shape(const char* who, int64_t n_rows, int32_t H, int32_t heads) {
@@ -391,4 +422,32 @@ extern "C" int agnn_hgt_attn_bwd_src_f32(const int32_t* rowptr, const int32_t* r
   else if (H <= 512) hipLaunchKernelGGL(k_hgt_bwd_src<2>, grid, block, 0, s, rowptr, rowend, col, perm, alpha, gs, a, dm, ld_dm, dk, dv, ld_o);
   else hipLaunchKernelGGL(k_hgt_bwd_src<4>, grid, block, 0, s, rowptr, rowend, col, perm, alpha, gs, a, dm, ld_dm, dk, dv, ld_o);
   return check_launch("hgt_bwd_src");
+}
+
+extern "C" int agnn_hgt_attn_bwd_src_batch_f32(int32_t n_items, const agnn_hgt_src_item_t* items, const float* q, int64_t ld_q,
+                                               const float* dm, int64_t ld_dm, int32_t H, int32_t heads, agnn_stream_t stream_) {
+  using namespace agnn;
+  if (n_items < 0 || n_items > AGNN_MAX_SEG || (n_items > 0 && !items)) return fail(AGNN_EINVAL, "hgt_bwd_src_batch: n_items=%d (0 .. %d)", n_items, AGNN_MAX_SEG);
+  if ((q && (!aligned16(q) || (ld_q & 3))) || (dm && (!aligned16(dm) || (ld_dm & 3)))) return fail(AGNN_EALIGN, "hgt_bwd_src_batch: misaligned matrix");
+  SrcBatch b{};
+  b.q = q; b.dm = dm; b.ld_q = ld_q; b.ld_dm = ld_dm; b.H = H; b.heads = heads;
+  int blocks = 0;
+  for (int i = 0; i < n_items; ++i) {
+    const agnn_hgt_src_item_t& it = items[i];
+    if (int rc = check_shape("hgt_bwd_src_batch", it.n_src_rows, H, heads)) return rc;
+    if (it.n_src_rows == 0) continue;
+    if (!it.rowptr || !it.dk || !it.dv) return fail(AGNN_EINVAL, "hgt_bwd_src_batch: item %d: null argument", i);
+    if (!aligned16(it.dk) || !aligned16(it.dv) || (it.ld_o & 3)) return fail(AGNN_EALIGN, "hgt_bwd_src_batch: item %d: misaligned output", i);
+    b.first[b.n] = blocks;
+    b.it[b.n++] = it;
+    blocks += static_cast<int>(grid_for(it.n_src_rows));
+  }
+  if (b.n == 0) return AGNN_OK;
+  b.first[b.n] = blocks;
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+  if (H <= 256) hipLaunchKernelGGL(k_hgt_bwd_src_batch<1>, grid, block, 0, s, b);
+  else if (H <= 512) hipLaunchKernelGGL(k_hgt_bwd_src_batch<2>, grid, block, 0, s, b);
+  else hipLaunchKernelGGL(k_hgt_bwd_src_batch<4>, grid, block, 0, s, b);
+  return check_launch("hgt_bwd_src_batch");
 }

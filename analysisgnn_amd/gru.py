@@ -24,10 +24,14 @@ PROJECTION_EVENTS: list = []
 def wait_for_projections(device) -> None:
     """Called by the graph stacks before their second layer: the current stream waits for the sequence branch's inner input
     projections issued so far (a no-op when there is no sequence branch, or it runs on this very stream)."""
-    while PROJECTION_EVENTS:
-        ev = PROJECTION_EVENTS.pop()
-        if torch.device(device).type == "cuda":
-            torch.cuda.current_stream(device).wait_event(ev)
+    device = torch.device(device)
+    if device.type != "cuda":
+        return
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    mine = [e for e in PROJECTION_EVENTS if e[0] == idx]
+    PROJECTION_EVENTS[:] = [e for e in PROJECTION_EVENTS if e[0] != idx]
+    for _, ev in mine:
+        torch.cuda.current_stream(device).wait_event(ev)
 
 
 class _GRULayer(torch.autograd.Function):
@@ -44,8 +48,9 @@ class _GRULayer(torch.autograd.Function):
         x2 = x.reshape(B * T, I)
         # 1-D bias: the library adds it in the GEMM epilogue (a [1, 6H] operand is first broadcast-copied into the 49 MB result)
         gi = torch.addmm(b_ih.reshape(-1), x2, w_ih.reshape(6 * Hh, I).t())         # [B*T, 2*3H]
-        if last_in_backward:
-            PROJECTION_EVENTS.clear()            # first layer of a new sequence pass: nobody collected the previous pass's events
+        dev_idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        if last_in_backward:                     # first layer of a new sequence pass: nobody collected the previous pass's events
+            PROJECTION_EVENTS[:] = [e for e in PROJECTION_EVENTS if e[0] != dev_idx]
         elif YIELD_TO_PROJECTIONS:
             # an inner layer's input projection sits between two recurrence kernels on the step's longest chain: whoever runs
             # GEMMs beside it (the GNN stack on the main stream, which has ~0.2 ms of slack) waits for this event instead of
@@ -53,7 +58,7 @@ class _GRULayer(torch.autograd.Function):
             # weight-gradient flush waiting for the inner dX projection — cost 0.09 ms and is not done.
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
-            PROJECTION_EVENTS.append(ev)
+            PROJECTION_EVENTS.append((dev_idx, ev))
         w_hh_c = w_hh.contiguous()
         b_hh_c = b_hh.contiguous()
         y = torch.empty((B, T, 2 * Hh), dtype=torch.float32, device=dev)

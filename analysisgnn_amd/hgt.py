@@ -425,6 +425,7 @@ class _HGTCore(torch.autograd.Function):
         written = set()                                              # relations whose dK' / dV' block a kernel has written
         zero_q = set()                                               # types whose dq is structurally zero
         dps_rows, dps_ids = [], []
+        keep_alive = []                      # row-end tensors referenced by a launch table until the launch is issued
         for ti, t in enumerate(plan.types):
             dm = dms[ti]
             n = plan.n_of[t]
@@ -454,6 +455,8 @@ class _HGTCore(torch.autograd.Function):
                        "agnn_hgt_attn_bwd_dst_f32")
             dps_rows.append(t3.sum(dim=2))
             dps_ids += [e_idx for e_idx, _ in rels]
+            src_items = (_lib.HgtSrcItem * len(rels))()
+            n_items = 0
             for r, (e_idx, et) in enumerate(rels):
                 s_t, blk = plan.block_of[e_idx]
                 c = plan.index.bwd[et]
@@ -461,12 +464,17 @@ class _HGTCore(torch.autograd.Function):
                 re = c.rowend(plan.limit(et))
                 lim = n if plan.index.fwd[et].n_rows > n else _lib.INT32_MAX
                 if n_src > 0:
-                    _lib.check(lib.agnn_hgt_attn_bwd_src_f32(c.rowptr.data_ptr(), _lib.ptr(re), c.col.data_ptr(), c.perm.data_ptr(),
-                                                             extra[r][0].data_ptr(), extra[r][1].data_ptr(), q.data_ptr() + 4 * H, q.stride(0),
-                                                             dm.data_ptr(), dm.stride(0), n_src, lim, H, heads,
-                                                             dkp[s_t].data_ptr() + 4 * blk * H, dvp[s_t].data_ptr() + 4 * blk * H,
-                                                             dkp[s_t].stride(0), st), "agnn_hgt_attn_bwd_src_f32")
+                    it = src_items[n_items]
+                    n_items += 1
+                    it.rowptr, it.rowend, it.col, it.perm = c.rowptr.data_ptr(), _lib.ptr(re), c.col.data_ptr(), c.perm.data_ptr()
+                    it.alpha, it.gs = extra[r][0].data_ptr(), extra[r][1].data_ptr()
+                    it.dk, it.dv = dkp[s_t].data_ptr() + 4 * blk * H, dvp[s_t].data_ptr() + 4 * blk * H
+                    it.ld_o, it.n_src_rows, it.col_limit = dkp[s_t].stride(0), n_src, lim
+                    keep_alive.append(re)
                 written.add(e_idx)
+            if n_items:                                   # every relation that ends in this type: one launch
+                _lib.check(lib.agnn_hgt_attn_bwd_src_batch_f32(n_items, src_items, q.data_ptr() + 4 * H, q.stride(0), dm.data_ptr(), dm.stride(0),
+                                                               H, heads, st), "agnn_hgt_attn_bwd_src_batch_f32")
         gwk = gwv = None
         wk_shape, wv_shape, p_shape = ctx.shapes
         later = ctx.wg_defer and dev.type == "cuda" and deferring(next(iter(X.values()))) and all_steal(ctx.steal_refs)

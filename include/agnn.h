@@ -247,6 +247,24 @@ int agnn_hgt_attn_bwd_src_f32(const int32_t* rowptr, const int32_t* rowend, cons
                               int64_t ld_q, const float* dm, int64_t ld_dm, int64_t n_src_rows,
                               int32_t col_limit, int32_t H, int32_t heads, float* dk, float* dv,
                               int64_t ld_o, agnn_stream_t stream);
+/* The same for up to AGNN_MAX_SEG relations in one launch — all relations ending in one destination type share q and dm; item i
+ * writes its own dk / dv (a column block of its source type's gradient).  Items are read on the host during the call. */
+typedef struct {
+  const int32_t* rowptr;
+  const int32_t* rowend;      /* NULL: rowptr + 1 */
+  const int32_t* col;
+  const int32_t* perm;
+  const float* alpha;
+  const float* gs;
+  float* dk;
+  float* dv;
+  int64_t ld_o;
+  int32_t n_src_rows;
+  int32_t col_limit;
+} agnn_hgt_src_item_t;
+int agnn_hgt_attn_bwd_src_batch_f32(int32_t n_items, const agnn_hgt_src_item_t* items /* (host) */, const float* q, int64_t ld_q,
+                                    const float* dm, int64_t ld_dm, int32_t H, int32_t heads, agnn_stream_t stream);
+
 
 /* ------------------------------------------------------------------------------------------
  * Edge-gated aggregation of the in-tree ResGatedGraphConv (ref: models/core/gnn.py:243-258):
