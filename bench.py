@@ -464,6 +464,10 @@ def main():
             keeps = [1.0, 0.75, 0.5] if args.flush_keep is None and hybrid else [_lin.FLUSH_KEEP]
             variants = [(a, b, k) for a in lates for b in homes for k in keeps]
             best = None
+            # every captured variant stays alive to the end of the run: letting the losers be destroyed (hipGraphExecDestroy + their
+            # private memory pools) crashed a LATER replay of the kept graph about every second run when a process group exists
+            # (capture_error_mode=thread_local, NCCL's watchdog thread alive; scripts/nccl_capture_check.py: 0 of 6 runs since)
+            keep_alive = []
             for late, home, keep in variants:
                 _enc.LATE_SEQUENCE_BACKWARD, _lin.ITEMS_HOME, _lin.FLUSH_KEEP = late, home, keep
                 g1 = torch.cuda.CUDAGraph()
@@ -486,6 +490,7 @@ def main():
                         g1.replay()
                     dp.barrier_and_sync()
                     t_v = dp.max_over_ranks(time.perf_counter() - t0)
+                keep_alive.append((g1, gt))
                 if best is None or t_v < best[0]:
                     best = (t_v, g1, loss_v, late, gt, home, keep)
             _, g1, loss_ref[0], schedule_late, g_tail, schedule_home, schedule_keep = best

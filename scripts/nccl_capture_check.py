@@ -31,6 +31,6 @@ for mode in ("global", "thread_local"):
     print(f"[nccl_capture_check] capture_error_mode={mode}: {'5 captures + replays ok' if ok else 'FAILED ' + why}", flush=True)
 # 2. the bench step itself (bench.py picks thread_local whenever a process group exists)
 import bench
-sys.argv = ["bench.py", "--no-cpu-baseline", "--no-other", "--steps", "20", "--warmup", "3"]
+sys.argv = ["bench.py", "--no-cpu-baseline", "--no-other", "--steps", "20", "--warmup", "3"] + os.environ.get("NCC_ARGS", "").split()
 bench.main()
 dist.destroy_process_group()
