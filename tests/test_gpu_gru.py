@@ -36,7 +36,8 @@ def _run(B, T, I, layers, seed, fast_oracle=False, hidden=128):
         assert_close(p.grad, P[n].grad, 1e-4, f"d{n}")
 
 
-@pytest.mark.parametrize("B,T,I,layers", [(1, 1, 8, 1), (3, 37, 64, 1), (2, 19, 256, 2), (5, 64, 32, 2)])
+@pytest.mark.parametrize("B,T,I,layers", [(1, 1, 8, 1), (2, 2, 8, 2), (2, 3, 8, 1), (1, 4, 8, 2), (3, 5, 16, 1), (2, 6, 8, 1), (2, 7, 8, 2),
+                                           (3, 37, 64, 1), (2, 19, 256, 2), (5, 64, 32, 2)])
 def test_gru_small(B, T, I, layers):
     _run(B, T, I, layers, seed=B * 100 + T)
 
