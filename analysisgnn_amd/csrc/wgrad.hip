@@ -64,6 +64,22 @@ __device__ __forceinline__ void wgrad_tile(const WgArgs& a, const int tile, cons
   // holds a single wave (256 x 256 outputs give one workgroup per CU).  The scheduling barrier after each fetch
   // keeps the compiler from hoisting the bias-sum adds of a chunk right behind its loads (which drained the queue).
   float2 a0[CH], b0[CH], a1[CH], b1[CH], a2[CH], b2[CH];
+  // Row offsets advance by two rows per k-step: running 32-bit byte offsets and ONE add per load.  (Computed from the row number
+  // each time, every load cost a clamp and a 64-bit multiply-add — v_mad_u64_u32, quarter rate: 32 of them per 32 MFMAs, ~700 cycles
+  // of address arithmetic per 2 048 cycles of matrix work in a wave that cannot issue an MFMA meanwhile.)  Chunks are fetched in
+  // order, so the offsets only move forward; the last chunks, which may reach past the end of the MATRIX, take the clamped path.
+  uint32_t o_dy = static_cast<uint32_t>(kk) * ldb_dy + cb_dy, o_x = static_cast<uint32_t>(kk) * ldb_x + cb_x;
+  const uint32_t s_dy = 2u * ldb_dy, s_x = 2u * ldb_x;
+  auto fetch_fast = [&](float2* ao, float2* bo) {     // the next chunk in order, entirely inside the matrix
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      ao[u] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(dy_s) + o_dy);
+      bo[u] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(x_s) + o_x);
+      o_dy += s_dy;
+      o_x += s_x;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
   auto fetch = [&](int chunk, float2* ao, float2* bo) {
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
@@ -71,6 +87,8 @@ __device__ __forceinline__ void wgrad_tile(const WgArgs& a, const int tile, cons
       ao[u] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(dy_s) + (rel * ldb_dy + cb_dy));
       bo[u] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(x_s) + (rel * ldb_x + cb_x));
     }
+    o_dy += CH * s_dy;                               // keeps the running offsets in step (not used past this point in practice)
+    o_x += CH * s_x;
     __builtin_amdgcn_sched_barrier(0);
   };
   auto mma = [&](const float2* av, const float2* bv) {
@@ -103,6 +121,15 @@ __device__ __forceinline__ void wgrad_tile(const WgArgs& a, const int tile, cons
   fetch(0, a0, b0);
   fetch(1, a1, b1);
   int c = 0;
+  const int safe = (rel_last + 1) / STEP;            // chunks [0, safe) lie entirely inside the matrix: no clamp needed
+  for (; c + 3 <= nfull && c + 5 <= safe; c += 3) {  // (the trip fetches chunks c + 2, c + 3, c + 4)
+    fetch_fast(a2, b2);
+    mma(a0, b0);
+    fetch_fast(a0, b0);
+    mma(a1, b1);
+    fetch_fast(a1, b1);
+    mma(a2, b2);
+  }
   for (; c + 3 <= nfull; c += 3) {
     fetch(c + 2, a2, b2);
     mma(a0, b0);
