@@ -320,3 +320,20 @@ def test_gemm_nt_matches_float64(M, N, K, bias):
     assert err < 5e-6, err
     assert float((c[:, N:] - 7.0).abs().max()) == 0.0            # nothing written past N
     assert lib.agnn_gemm_nt_f32(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), None, M, N + 1, K, c.data_ptr(), c.stride(0), None) < 0
+
+
+def test_pack_zero_fills_pieces_without_sources():
+    """agnn_pack_f32: an item with n_src = 0 clears its destination piece (strided column blocks included) and leaves the rest alone."""
+    from analysisgnn_amd.params import pack
+    dev = torch.device("cuda", 0)
+    a = torch.full((37, 48), 7.0, device=dev)
+    b = torch.full((5, 12), 3.0, device=dev)
+    src = torch.arange(37 * 16, dtype=torch.float32, device=dev).view(37, 16)
+    pack([(a[:, 8:24], []), (b[2:4], []), (a[:, 32:48], [src, src])], dev)
+    want = torch.full((37, 48), 7.0, device=dev)
+    want[:, 8:24] = 0
+    want[:, 32:48] = 2 * src
+    assert torch.equal(a, want)
+    wb = torch.full((5, 12), 3.0, device=dev)
+    wb[2:4] = 0
+    assert torch.equal(b, wb)

@@ -400,3 +400,62 @@ def test_split_backward_two_buckets_equal_the_unsplit_step():
         dp.defer_weight_grads(False)
         dp.enable_wgrad_overlap(False)
         graph.index_cache_enabled = was
+
+
+@pytest.mark.parametrize("enc", ["hybridgnn", "hgt"])
+def test_every_backward_schedule_switch_gives_the_same_gradients(enc):
+    """bench.py captures the step under up to 12 schedule variants and keeps the fastest replay: {sequence branch behind a late
+    node / in autograd order} x {its deferred products in the main flush / in its own} x {all / 3/4 / half of the main flush's
+    products at the flush point, the rest on the sequence branch's stream}; the graph stack's second layer may wait for the GRU's
+    inner input projection.  Every combination must produce the plain (nothing deferred) step's loss exactly and its gradients
+    to fp32 rounding (batched products sum in another order), and must itself be reproducible bit for bit.  HGT: the relation
+    weights' gradients are among the deferred products."""
+    from analysisgnn_amd import dp, encoders, graph, gru, linear
+    from analysisgnn_amd.heads import MultiTaskLoss, training_loss
+    from analysisgnn_amd.models import TorchAnalysisGNN
+    from analysisgnn_amd.synth import make_batch, make_score_graph, merge_sampled, sample_hops, torch_inputs
+    dev = torch.device("cuda", 0)
+    tasks = {"cadence": 4, "localkey": 50, "hrythm": 2}
+    if enc == "hgt":
+        g = make_batch(3, 150, first_seed=11, add_beats=True, add_measures=True, reverse_metrical_edges=True)
+    else:
+        g = merge_sampled([sample_hops(make_score_graph(seed=sd, n_notes=400), 150, (5, 5), seed=sd, first_target=20) for sd in (1, 2, 3)])
+    I = torch_inputs(g, 25, dev, seed=0)
+    labels = torch.stack([torch.randint(0, c, (I["batch_size"],), generator=torch.Generator().manual_seed(i)).to(dev)
+                          for i, c in enumerate(tasks.values())])
+    torch.manual_seed(0)
+    model = TorchAnalysisGNN(g.metadata(), 25, 256, 128, tasks, 3, dropout=0.0, use_jk=False, logit_fusion=False, encoder_type=enc).to(dev).train()
+    clf = MultiTaskLoss(list(tasks)).to(dev)
+    flat = dp.FlatGradBuffer(torch.nn.ModuleDict({"m": model, "c": clf}).parameters(), views=False)
+    saved = (graph.index_cache_enabled, encoders.LATE_SEQUENCE_BACKWARD, linear.ITEMS_HOME, linear.FLUSH_KEEP, gru.YIELD_TO_PROJECTIONS)
+    graph.index_cache_enabled = False
+
+    def fwd_bwd():
+        flat.zero()
+        x = model.encode(I["pitch_spelling"], I["key_signature"], I["x_dict"], I["edge_index_dict"], I["batch_dict"], I["batch_size"],
+                         I["neighbor_mask_node"], I["neighbor_mask_edge"])
+        logits, offs, _ = model.forward_clf_fused(x)
+        loss, _ = training_loss(logits, offs, labels, x, 0.1, 0.1, -1, task_params=clf.weights())
+        loss.backward()
+        flat.pack()
+        torch.cuda.synchronize()
+        return float(loss), flat.flat.clone()
+    try:
+        gru.YIELD_TO_PROJECTIONS = False
+        l0, g0 = fwd_bwd()
+        assert torch.isfinite(g0).all() and float(g0.abs().max()) > 0
+        dp.defer_weight_grads(True)
+        for late in (True, False):
+            for home in (True, False):
+                for keep in (1.0, 0.75, 0.5, 0.0):
+                    for yld in ((True, False) if (late, home, keep) == (True, True, 0.75) else (True,)):
+                        encoders.LATE_SEQUENCE_BACKWARD, linear.ITEMS_HOME, linear.FLUSH_KEEP, gru.YIELD_TO_PROJECTIONS = late, home, keep, yld
+                        what = f"late={late} home={home} keep={keep} yield={yld}"
+                        l1, g1 = fwd_bwd()
+                        assert l1 == l0, what
+                        _same_to_rounding(g1, g0, what)
+                        l2, g2 = fwd_bwd()
+                        assert l2 == l1 and torch.equal(g2, g1), what
+    finally:
+        dp.defer_weight_grads(False)
+        graph.index_cache_enabled, encoders.LATE_SEQUENCE_BACKWARD, linear.ITEMS_HOME, linear.FLUSH_KEEP, gru.YIELD_TO_PROJECTIONS = saved
