@@ -49,11 +49,12 @@ __device__ __forceinline__ float tanhf_(float x) { return 2.f * __builtin_amdgcn
 //   phase 1 (all 8 waves; wave = one 16-wide k chunk of W_hh, lane = six of its 384 rows): the wave's h chunk from LDS
 //            (one address for all lanes), 48 packed FMAs, six partial sums to LDS (part[kc][gate][unit], no cross-lane
 //            reduction at all);
-//   phase 2 (waves 0 and 1, one lane per hidden unit): add the 8 partials per gate in a fixed order, gates, h_t to LDS,
-//            the five per-step outputs to HBM (coalesced over units), prefetch of the input projections 4 steps ahead.
-// Waves 2-7 run a loop that contains phase 1 only, so the loop of the unit-lane waves is straight-line code with
-// unconditional loads / stores and counted s_waitcnt (a branch around a memory operation makes the compiler wait for
-// ALL outstanding operations at the join, which put one memory round trip into every step).
+//   phase 2 (waves 0 and 1, one lane per hidden unit): add the 8 partials per gate in a fixed order, gates, h_t to LDS.
+//            Round 3: these unit lanes touch LDS only — the step's operands arrive in an LDS ring filled by a LOADER wave
+//            pair and its outputs leave through LDS and a STORER pair (see "roles" in the kernel).
+// Every wave's loop is straight-line code with unconditional loads / stores and counted s_waitcnt (a branch around a
+// memory operation makes the compiler wait for ALL outstanding operations at the join, which put one memory round trip into
+// every step).
 // Tried, slower: two EXTRA waves for phase 2 (640 threads) with their stores deferred behind the second barrier.
 
 // Inter-layer dropout rides along (nn.GRU(dropout=p), models/cadence.py:249-251): `drop` [B, T, 2*HH] holds 0 or 1 / (1 - p)
@@ -112,9 +113,9 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
   };
 
   // ---- roles.  The unit lanes (tid < HH: waves 0 and 1) touch LDS only; ALL global loads and stores of a step are done by
-  // helper lanes (tid 128 .. 128 + HH: waves 2 and 3, SIMDs that idle during phase 2) in the window where they would wait at the
-  // barrier: the input projections travel memory -> loader registers (two sets, requested 4 steps ahead) -> LDS ring `s_in` (2
-  // steps ahead) -> phase 2; the step's outputs travel phase 2 -> `s_out` -> helper -> memory one step later.  With the loads,
+  // helper lanes (loader: tid 128 .. 128 + HH = waves 2 and 3; storer: tid 384 .. = waves 6 and 7; SIMDs that idle during phase 2) in the window where they would wait at the
+  // barrier: the input projections travel memory -> loader registers (four sets, requested 6 steps ahead) -> LDS ring `s_in` (2
+  // steps ahead) -> phase 2; the step's outputs travel phase 2 -> `s_out` -> storer -> memory one step later.  With the loads,
   // stores and their address arithmetic inside phase 2 the step took 1 474 cycles, without them 1 310 (ablation, profiles/
   // r03_gru.md) — and beside another kernel's memory traffic the unit lanes additionally waited for their stores to be
   // acknowledged before a prefetched operand could be used (loads and stores share one in-order counter).
