@@ -50,8 +50,8 @@ __device__ __forceinline__ float tanhf_(float x) { return 2.f * __builtin_amdgcn
 //            (one address for all lanes), 48 packed FMAs, six partial sums to LDS (part[kc][gate][unit], no cross-lane
 //            reduction at all);
 //   phase 2 (waves 0 and 1, one lane per hidden unit): add the 8 partials per gate in a fixed order, gates, h_t to LDS.
-//            Round 3: these unit lanes touch LDS only — the step's operands arrive in an LDS ring filled by a LOADER wave
-//            pair and its outputs leave through LDS and a STORER pair (see "roles" in the kernel).
+//            Round 3: the unit lanes issue no global load — the step's operands arrive in an LDS ring filled by a LOADER
+//            wave pair (see "roles" in the kernel); in the backward kernel the results also leave through LDS and a STORER pair.
 // Every wave's loop is straight-line code with unconditional loads / stores and counted s_waitcnt (a branch around a
 // memory operation makes the compiler wait for ALL outstanding operations at the join, which put one memory round trip into
 // every step).
@@ -73,7 +73,6 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
   __shared__ __attribute__((aligned(16))) float hbuf[2][HH];
   __shared__ __attribute__((aligned(16))) float part[KC * PSTR];
   __shared__ float s_in[4][4][HH];        // ring of 4 steps: gi_r, gi_z, gi_n, dropout factor — written by the helper lanes
-  __shared__ float s_out[2][5][HH];       // the last two steps' y * factor, r, z, n, W_hn h + b_hn — written by phase 2
   CLAIM_SIMD_REGISTERS();
   const int b = blockIdx.x >> 1, d = blockIdx.x & 1;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -112,16 +111,16 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
     }
   };
 
-  // ---- roles.  The unit lanes (tid < HH: waves 0 and 1) touch LDS only; ALL global loads and stores of a step are done by
-  // helper lanes (loader: tid 128 .. 128 + HH = waves 2 and 3; storer: tid 384 .. = waves 6 and 7; SIMDs that idle during phase 2) in the window where they would wait at the
-  // barrier: the input projections travel memory -> loader registers (four sets, requested 6 steps ahead) -> LDS ring `s_in` (2
-  // steps ahead) -> phase 2; the step's outputs travel phase 2 -> `s_out` -> storer -> memory one step later.  With the loads,
-  // stores and their address arithmetic inside phase 2 the step took 1 474 cycles, without them 1 310 (ablation, profiles/
-  // r03_gru.md) — and beside another kernel's memory traffic the unit lanes additionally waited for their stores to be
-  // acknowledged before a prefetched operand could be used (loads and stores share one in-order counter).
+  // ---- roles.  The unit lanes (tid < HH: waves 0 and 1) issue NO global load: the step's operands are brought by loader lanes
+  // (tid 128 .. 128 + HH = waves 2 and 3, SIMDs that idle during phase 2) in the window where those would wait at the barrier:
+  // memory -> loader registers (four sets, requested 6 steps ahead) -> LDS ring `s_in` (2 steps ahead) -> phase 2.  With the
+  // loads, stores and their address arithmetic inside phase 2 the step took 1 474 cycles, without them 1 310 (ablation,
+  // profiles/r03_gru.md) — and beside another kernel's memory traffic the unit lanes additionally waited for their stores to be
+  // acknowledged before a prefetched operand could be used (loads and stores share one in-order counter).  Without loads of
+  // their own the unit lanes' stores are never waited for, so the five outputs leave from phase 2 directly (through LDS and a
+  // storer wave pair, as in the backward kernel, the hand-over cost as much as the stores: 301 vs 298 us per launch).
   const bool loader = tid >= 128 && tid < 128 + HH;         // waves 2, 3: operands in
-  const bool storer = tid >= 384 && tid < 384 + HH;         // waves 6, 7 (the same SIMDs' second waves): results out
-  const int hu = tid - (loader ? 128 : 384);
+  const int hu = tid - 128;
   const size_t row3 = static_cast<size_t>(2) * 3 * HH;
   auto load_in = [&](int s_, float (&g3)[4]) {
     const int sc = s_ < T ? s_ : T - 1;
@@ -139,19 +138,6 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
     q[2 * HH] = g3[2];
     q[3 * HH] = g3[3];
   };
-  auto store_out = [&](int s_) {           // outputs of step s_ (>= 0): h_t from hbuf, the rest from sout
-    const int t = d ? T - 1 - s_ : s_;
-    const size_t bt = static_cast<size_t>(b) * T + t;
-    const float* o = &s_out[s_ & 1][0][hu];
-    y[bt * 2 * HH + d * HH + hu] = hbuf[(s_ + 1) & 1][hu];
-    y2[bt * 2 * HH + d * HH + hu] = o[0];
-    float* sv = saved + (bt * 2 + d) * 4 * HH + hu;
-    sv[0] = o[HH];
-    sv[HH] = o[2 * HH];
-    sv[2 * HH] = o[3 * HH];
-    sv[3 * HH] = o[4 * HH];
-  };
-
   // window s = while the unit lanes run phase 2 of step s
   if (loader) {                          // step s + 2's operands -> LDS, step s + 6's requested: four register sets in flight,
     float g0[4], g1[4], g2[4], g3[4];    // ~2.4 us between request and use (two sets stalled the barrier beside the other
@@ -176,17 +162,6 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
     if (s + 2 < T) { phase1(0); lds_barrier(); lds_barrier(); }
     return;
   }
-  if (storer) {                          // step s - 1's outputs -> memory (window 0 stores step 0's slots with whatever LDS holds and
-    __syncthreads();                     // window 1 overwrites them: no branch around a memory operation in this loop — the compiler
-    int s = 0;                           // would wait for ALL outstanding operations at the join)
-    for (; s + 2 <= T; s += 2) {
-      phase1(0); lds_barrier(); store_out(s > 0 ? s - 1 : 0); lds_barrier();
-      phase1(1); lds_barrier(); store_out(s);                 lds_barrier();
-    }
-    if (s < T) { phase1(0); lds_barrier(); store_out(s > 0 ? s - 1 : 0); lds_barrier(); }
-    store_out(T - 1);
-    return;
-  }
   if (tid >= HH) {                       // the other waves: mat-vec only
     __syncthreads();
     int s = 0;
@@ -202,6 +177,12 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
   const int u = tid;
   const float bh0 = b_hh[d * 3 * HH + u], bh1 = b_hh[d * 3 * HH + HH + u], bh2 = b_hh[d * 3 * HH + 2 * HH + u];
   float hprev = 0.f;
+  // running output pointers: time step 0 of this direction, then one row forward (reverse direction: backward) per step
+  const int64_t t0 = d ? T - 1 : 0;
+  const int64_t y_step = (d ? -1 : 1) * static_cast<int64_t>(2 * HH), sv_step = (d ? -1 : 1) * static_cast<int64_t>(2 * 4 * HH);
+  float* y_p = y + (static_cast<size_t>(b) * T + t0) * 2 * HH + d * HH + u;
+  float* y2_p = y2 + (static_cast<size_t>(b) * T + t0) * 2 * HH + d * HH + u;
+  float* sv_p = saved + ((static_cast<size_t>(b) * T + t0) * 2 + d) * 4 * HH + u;
   auto phase2 = [&](int cur, int slot) {         // cur = s & 1, slot = s & 3: constants in the unrolled loop below
     float p0[KC], p1[KC], p2[KC];
 #pragma unroll
@@ -222,12 +203,17 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
     const float hnew = (1.f - zz) * nn + zz * hprev;
     hprev = hnew;
     hbuf[cur ^ 1][u] = hnew;
-    float* o = &s_out[cur][0][u];
-    o[0] = hnew * fac;
-    o[HH] = rr;
-    o[2 * HH] = zz;
-    o[3 * HH] = nn;
-    o[4 * HH] = s2;
+    // the unit lanes issue no load at all, so their stores are never waited for (vmcnt only matters to a load's consumer): the
+    // five per-step outputs leave from here (through LDS and a storer wave pair the hand-over cost as much as these stores)
+    y_p[0] = hnew;
+    y2_p[0] = hnew * fac;
+    sv_p[0] = rr;
+    sv_p[HH] = zz;
+    sv_p[2 * HH] = nn;
+    sv_p[3 * HH] = s2;
+    y_p += y_step;
+    y2_p += y_step;
+    sv_p += sv_step;
   };
   __syncthreads();
   int s = 0;
