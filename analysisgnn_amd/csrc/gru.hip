@@ -67,22 +67,28 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
                                                  const float* __restrict__ b_hh, int T, float* __restrict__ y,
                                                  float* __restrict__ saved, const float* __restrict__ drop, float use,
                                                  float* __restrict__ y2) {
-  constexpr int PSTR = 3 * HH;           // part[kc][gate*HH + unit]
-  constexpr int RPL = 3 * HH / 64;       // rows of W_hh per lane (6 at HH = 128, 3 at 64)
-  constexpr int CPW = HH / KC;           // columns of W_hh per wave (16 / 8)
+  constexpr int PSTR = 3 * HH;           // part[ks][gate*HH + unit]
+  // the 8 waves split the mat-vec KS ways along k and RS ways along the rows.  HH = 128: 4 x 2 — four partial sums per row
+  // instead of eight: phase 2 (the two waves that carry the serial chain) reads 12 LDS words per unit instead of 24, phase 1
+  // writes 3 per lane instead of 6 (8 x 1 before: 301 -> 2xx us per launch); HH = 64: 8 x 1 (3 rows per lane either way)
+  constexpr int KS = HH == 128 ? 4 : 8, RS = KC / KS;
+  constexpr int RPL = 3 * HH / (64 * RS);  // rows of W_hh per lane (3)
+  constexpr int CPW = HH / KS;             // columns of W_hh per wave (32 / 8)
   __shared__ __attribute__((aligned(16))) float hbuf[2][HH];
-  __shared__ __attribute__((aligned(16))) float part[KC * PSTR];
+  __shared__ __attribute__((aligned(16))) float part[KS * PSTR];
   __shared__ float s_in[4][4][HH];        // ring of 4 steps: gi_r, gi_z, gi_n, dropout factor — written by the helper lanes
   CLAIM_SIMD_REGISTERS();
   const int b = blockIdx.x >> 1, d = blockIdx.x & 1;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int kc = __builtin_amdgcn_readfirstlane(tid >> 6);       // this WAVE's k chunk: its h values are wave-uniform
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kc = wv % KS;                                        // this WAVE's k chunk: its h values are wave-uniform
+  const int row0 = (wv / KS) * (3 * HH / RS) + lane;             // ... and its block of rows
   const float* W = w_hh + static_cast<size_t>(d) * 3 * HH * HH;
-  // lane -> the RPL rows {lane + 64 i} of W_hh (row = gate*HH + unit), columns [CPW kc, CPW kc + CPW)
+  // lane -> the RPL rows {row0 + 64 i} of W_hh (row = gate*HH + unit), columns [CPW kc, CPW kc + CPW)
   f32x2 w[RPL][CPW / 2];
 #pragma unroll
   for (int i = 0; i < RPL; ++i) {
-    const float4* src = reinterpret_cast<const float4*>(W + static_cast<size_t>(lane + 64 * i) * HH + CPW * kc);
+    const float4* src = reinterpret_cast<const float4*>(W + static_cast<size_t>(row0 + 64 * i) * HH + CPW * kc);
 #pragma unroll
     for (int v = 0; v < CPW / 4; ++v) {
       const float4 t4 = src[v];
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
       f32x2 a = {0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < CPW / 2; ++k) a = __builtin_elementwise_fma(w[i][k], hk[k], a);
-      part[kc * PSTR + lane + 64 * i] = a.x + a.y;             // consecutive lanes, consecutive words: conflict-free
+      part[kc * PSTR + row0 + 64 * i] = a.x + a.y;             // consecutive lanes, consecutive words: conflict-free
     }
   };
 
@@ -184,19 +190,26 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
   float* y2_p = y2 + (static_cast<size_t>(b) * T + t0) * 2 * HH + d * HH + u;
   float* sv_p = saved + ((static_cast<size_t>(b) * T + t0) * 2 + d) * 4 * HH + u;
   auto phase2 = [&](int cur, int slot) {         // cur = s & 1, slot = s & 3: constants in the unrolled loop below
-    float p0[KC], p1[KC], p2[KC];
+    float p0[KS], p1[KS], p2[KS];
 #pragma unroll
-    for (int k = 0; k < KC; ++k) {
+    for (int k = 0; k < KS; ++k) {
       p0[k] = part[k * PSTR + u];
       p1[k] = part[k * PSTR + HH + u];
       p2[k] = part[k * PSTR + 2 * HH + u];
     }
     const float* in = &s_in[slot][0][u];
     const float gi0 = in[0], gi1 = in[HH], gi2 = in[2 * HH], fac = in[3 * HH];
-    // fixed-shape tree (depth 3 instead of a chain of 8 dependent adds; same order every run: bitwise reproducible)
-    const float s0 = (((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p0[4] + p0[5]) + (p0[6] + p0[7]))) + bh0;
-    const float s1 = (((p1[0] + p1[1]) + (p1[2] + p1[3])) + ((p1[4] + p1[5]) + (p1[6] + p1[7]))) + bh1;
-    const float s2 = (((p2[0] + p2[1]) + (p2[2] + p2[3])) + ((p2[4] + p2[5]) + (p2[6] + p2[7]))) + bh2;
+    // fixed-shape tree (same order every run: bitwise reproducible)
+    float s0, s1, s2;
+    if (KS == 4) {
+      s0 = ((p0[0] + p0[1]) + (p0[2] + p0[3])) + bh0;
+      s1 = ((p1[0] + p1[1]) + (p1[2] + p1[3])) + bh1;
+      s2 = ((p2[0] + p2[1]) + (p2[2] + p2[3])) + bh2;
+    } else {
+      s0 = (((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p0[4 % KS] + p0[5 % KS]) + (p0[6 % KS] + p0[7 % KS]))) + bh0;
+      s1 = (((p1[0] + p1[1]) + (p1[2] + p1[3])) + ((p1[4 % KS] + p1[5 % KS]) + (p1[6 % KS] + p1[7 % KS]))) + bh1;
+      s2 = (((p2[0] + p2[1]) + (p2[2] + p2[3])) + ((p2[4 % KS] + p2[5 % KS]) + (p2[6 % KS] + p2[7 % KS]))) + bh2;
+    }
     const float rr = sigmoidf_(gi0 + s0);
     const float zz = sigmoidf_(gi1 + s1);
     const float nn = tanhf_(gi2 + rr * s2);
