@@ -3,7 +3,7 @@
 import csv, glob, statistics, sys
 pat, path = sys.argv[1], sys.argv[2]
 acc = {}
-for f in sorted(glob.glob(path)):
+for f in sorted(glob.glob(path, recursive=True)):
     for r in csv.DictReader(open(f)):
         if pat in r["Kernel_Name"]:
             k = (r["Kernel_Name"][:70].replace(",", ";"), r["Counter_Name"], r["Grid_Size"])

@@ -10,7 +10,7 @@ rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r3_prof_spmm -o s --output-for
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/r3_pmc_fetch -o p --output-format csv -- python3 $R/scripts/spmm_trim_case.py 256 > $R/gpurun_out/r3_pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/r3_pmc_write -o p --output-format csv -- python3 $R/scripts/spmm_trim_case.py 256 > $R/gpurun_out/r3_pmc_write.log 2>&1
 cd $R
-for d in r3_pmc_fetch r3_pmc_write; do python3 scripts/pmc_summary.py k_spmm "gpurun_out/$d/*/*counter_collection.csv"; done > gpurun_out/r3_spmm_pmc_summary.txt 2>&1 || true
+for d in r3_pmc_fetch r3_pmc_write; do python3 scripts/pmc_summary.py k_spmm "gpurun_out/$d/**/*counter_collection.csv"; done > gpurun_out/r3_spmm_pmc_summary.txt 2>&1 || true
 python3 scripts/step_timeline.py gpurun_out/r3_prof_bench/b_kernel_trace.csv > gpurun_out/r3_step_timeline_c2s.txt 2>&1 || true
 # what travels back is capped at 64 MiB: keep the summaries, drop the raw traces and counter dumps
 find gpurun_out/r3_prof_bench gpurun_out/r3_prof_c3d gpurun_out/r3_prof_spmm gpurun_out/r3_pmc_fetch gpurun_out/r3_pmc_write \( -name "*kernel_trace.csv" -o -name "*counter_collection.csv" \) -delete
