@@ -146,26 +146,24 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
   };
   // window s = while the unit lanes run phase 2 of step s
   if (loader) {                          // step s + 2's operands -> LDS, step s + 6's requested: four register sets in flight,
-    float g0[4], g1[4], g2[4], g3[4];    // ~2.4 us between request and use (two sets stalled the barrier beside the other
-    load_in(0, g0);                      // branch's weight-gradient traffic)
+    float g0[4], g1[4], g2[4], g3[4], g4[4], g5[4], g6[4], g7[4];    // eight register sets: ~4.4 us between request and use
+    load_in(0, g0);
     load_in(1, g1);
     put_in(0, g0);
     put_in(1, g1);
-    load_in(2, g2);
-    load_in(3, g3);
-    load_in(4, g0);
-    load_in(5, g1);
+    load_in(2, g2); load_in(3, g3); load_in(4, g4); load_in(5, g5); load_in(6, g6); load_in(7, g7);
+    load_in(8, g0); load_in(9, g1);
     __syncthreads();
     int s = 0;
-    for (; s + 4 <= T; s += 4) {
-      phase1(0); lds_barrier(); put_in(s + 2, g2); load_in(s + 6, g2); lds_barrier();
-      phase1(1); lds_barrier(); put_in(s + 3, g3); load_in(s + 7, g3); lds_barrier();
-      phase1(0); lds_barrier(); put_in(s + 4, g0); load_in(s + 8, g0); lds_barrier();
-      phase1(1); lds_barrier(); put_in(s + 5, g1); load_in(s + 9, g1); lds_barrier();
+#define GRU_FWD_WINDOW(I, G) phase1((I) & 1); lds_barrier(); put_in(s + 2 + (I), G); load_in(s + 10 + (I), G); lds_barrier();
+    for (; s + 8 <= T; s += 8) {
+      GRU_FWD_WINDOW(0, g2) GRU_FWD_WINDOW(1, g3) GRU_FWD_WINDOW(2, g4) GRU_FWD_WINDOW(3, g5)
+      GRU_FWD_WINDOW(4, g6) GRU_FWD_WINDOW(5, g7) GRU_FWD_WINDOW(6, g0) GRU_FWD_WINDOW(7, g1)
     }
-    if (s < T)     { phase1(0); lds_barrier(); put_in(s + 2, g2); lds_barrier(); }
-    if (s + 1 < T) { phase1(1); lds_barrier(); lds_barrier(); }
-    if (s + 2 < T) { phase1(0); lds_barrier(); lds_barrier(); }
+#undef GRU_FWD_WINDOW
+#define GRU_FWD_LAST(I, G) if (s + (I) < T) { phase1((I) & 1); lds_barrier(); put_in(s + 2 + (I), G); lds_barrier(); }
+    GRU_FWD_LAST(0, g2) GRU_FWD_LAST(1, g3) GRU_FWD_LAST(2, g4) GRU_FWD_LAST(3, g5) GRU_FWD_LAST(4, g6) GRU_FWD_LAST(5, g7) GRU_FWD_LAST(6, g0)
+#undef GRU_FWD_LAST
     return;
   }
   if (tid >= HH) {                       // the other waves: mat-vec only
