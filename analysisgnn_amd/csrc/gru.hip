@@ -135,14 +135,14 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
     g3[0] = p[0];
     g3[1] = p[HH];
     g3[2] = p[2 * HH];
-    g3[3] = fmaf(use, drop[(static_cast<size_t>(b) * T + t_) * 2 * HH + d * HH + hu] - 1.f, 1.f);       // the factor itself
+    g3[3] = drop[(static_cast<size_t>(b) * T + t_) * 2 * HH + d * HH + hu];       // raw: arithmetic on a loaded value waits until put_in
   };
   auto put_in = [&](int s_, const float (&g3)[4]) {
     float* q = &s_in[s_ & 3][0][hu];
     q[0] = g3[0];
     q[HH] = g3[1];
     q[2 * HH] = g3[2];
-    q[3 * HH] = g3[3];
+    q[3 * HH] = fmaf(use, g3[3] - 1.f, 1.f);       // the factor itself
   };
   // window s = while the unit lanes run phase 2 of step s
   if (loader) {                          // step s + 2's operands -> LDS, step s + 6's requested: four register sets in flight,
@@ -297,13 +297,14 @@ __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, co
   const bool loader = tid >= 128 && tid < 128 + HH;         // waves 2, 3: operands in (and h_{t-1} out)
   const bool storer = tid >= 384 && tid < 384 + HH;         // waves 6, 7: gate gradients out
   const int hu = tid - (loader ? 128 : 384);
-  struct StepIn { float dyv, r, z, n, q, hp; };
+  struct StepIn { float dyv, dr, r, z, n, q, hp; };      // raw loaded values: arithmetic on them waits until put_in
   auto load_in = [&](int s_, StepIn& o) {
     const int sc = s_ < T ? s_ : T - 1;
     const int t_ = d ? sc : T - 1 - sc;          // reverse of the forward walk
     const int tp_ = d ? t_ + 1 : t_ - 1;
     const size_t bt_ = static_cast<size_t>(b) * T + t_;
-    o.dyv = dy[bt_ * 2 * HH + d * HH + hu] * fmaf(use, drop[bt_ * 2 * HH + d * HH + hu] - 1.f, 1.f);   // dy is d(y * drop)
+    o.dyv = dy[bt_ * 2 * HH + d * HH + hu];
+    o.dr = drop[bt_ * 2 * HH + d * HH + hu];
     const float* sv = saved + (bt_ * 2 + d) * 4 * HH + hu;
     o.r = sv[0];
     o.z = sv[HH];
@@ -311,20 +312,23 @@ __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, co
     o.q = sv[3 * HH];
     const bool has_prev = tp_ >= 0 && tp_ < T;
     const int tpc = has_prev ? tp_ : t_;
-    o.hp = y[(static_cast<size_t>(b) * T + tpc) * 2 * HH + d * HH + hu] * (has_prev ? 1.f : 0.f);
+    o.hp = y[(static_cast<size_t>(b) * T + tpc) * 2 * HH + d * HH + hu];
   };
   auto put_in = [&](int s_, const StepIn& o) {
     float* q = &s_in[s_ & 3][0][hu];
-    q[0] = o.dyv;
+    const int sp = s_ < T ? s_ : T - 1;
+    const int tq = d ? sp + 1 : T - 2 - sp;      // the time step h_{t-1} came from: outside the sequence at its first step
+    const float hp = (tq >= 0 && tq < T) ? o.hp : 0.f;
+    q[0] = o.dyv * fmaf(use, o.dr - 1.f, 1.f);   // dy is d(y * drop)
     q[HH] = o.r;
     q[2 * HH] = o.z;
     q[3 * HH] = o.n;
     q[4 * HH] = o.q;
-    q[5 * HH] = o.hp;
+    q[5 * HH] = hp;
     if (HP) {                                    // compile-time: no branch around a memory operation in the loop; a step index
       const int sc = s_ < T ? s_ : T - 1;        // past the end repeats the last step's (identical) store
       const int t_ = d ? sc : T - 1 - sc;
-      hp_out[((static_cast<size_t>(b) * T + t_) * 2 + d) * HH + hu] = o.hp;
+      hp_out[((static_cast<size_t>(b) * T + t_) * 2 + d) * HH + hu] = hp;
     }
   };
   auto store_out = [&](int s_) {
@@ -343,27 +347,25 @@ __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, co
   };
 
   // window s = while the unit lanes run phase A of step s
-  if (loader) {                          // four register sets in flight: requested 6 steps ahead, to LDS 2 steps ahead
-    StepIn i0, i1, i2, i3;
+  if (loader) {                          // eight register sets in flight: requested 10 steps ahead, to LDS 2 steps ahead
+    StepIn i0, i1, i2, i3, i4, i5, i6, i7;
     load_in(0, i0);
     load_in(1, i1);
     put_in(0, i0);
     put_in(1, i1);
-    load_in(2, i2);
-    load_in(3, i3);
-    load_in(4, i0);
-    load_in(5, i1);
+    load_in(2, i2); load_in(3, i3); load_in(4, i4); load_in(5, i5); load_in(6, i6); load_in(7, i7);
+    load_in(8, i0); load_in(9, i1);
     __syncthreads();
     int s = 0;
-    for (; s + 4 <= T; s += 4) {
-      put_in(s + 2, i2); load_in(s + 6, i2); lds_barrier(); phaseB(0); lds_barrier();
-      put_in(s + 3, i3); load_in(s + 7, i3); lds_barrier(); phaseB(1); lds_barrier();
-      put_in(s + 4, i0); load_in(s + 8, i0); lds_barrier(); phaseB(0); lds_barrier();
-      put_in(s + 5, i1); load_in(s + 9, i1); lds_barrier(); phaseB(1); lds_barrier();
+#define GRU_BWD_WINDOW(I, G) put_in(s + 2 + (I), G); load_in(s + 10 + (I), G); lds_barrier(); phaseB((I) & 1); lds_barrier();
+    for (; s + 8 <= T; s += 8) {
+      GRU_BWD_WINDOW(0, i2) GRU_BWD_WINDOW(1, i3) GRU_BWD_WINDOW(2, i4) GRU_BWD_WINDOW(3, i5)
+      GRU_BWD_WINDOW(4, i6) GRU_BWD_WINDOW(5, i7) GRU_BWD_WINDOW(6, i0) GRU_BWD_WINDOW(7, i1)
     }
-    if (s < T)     { put_in(s + 2, i2); lds_barrier(); phaseB(0); lds_barrier(); }
-    if (s + 1 < T) { lds_barrier(); phaseB(1); lds_barrier(); }
-    if (s + 2 < T) { lds_barrier(); phaseB(0); lds_barrier(); }
+#undef GRU_BWD_WINDOW
+#define GRU_BWD_LAST(I, G) if (s + (I) < T) { put_in(s + 2 + (I), G); lds_barrier(); phaseB((I) & 1); lds_barrier(); }
+    GRU_BWD_LAST(0, i2) GRU_BWD_LAST(1, i3) GRU_BWD_LAST(2, i4) GRU_BWD_LAST(3, i5) GRU_BWD_LAST(4, i6) GRU_BWD_LAST(5, i7) GRU_BWD_LAST(6, i0)
+#undef GRU_BWD_LAST
     return;
   }
   if (storer) {
