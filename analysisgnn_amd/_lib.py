@@ -187,6 +187,10 @@ SIGNATURES = {
                                       C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                       C.c_void_p]),
+    "agnn_train_loss_final_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_float, C.c_int64,
+                                            C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                            C.c_size_t, C.c_void_p]),
     "agnn_train_loss_bwd_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_int64,
                                           C.c_void_p]),

@@ -60,7 +60,8 @@ __device__ __forceinline__ void task_regs(PZ zr, PD dr, int a, int b, int sub, i
 // all tasks of one row (16 lanes): zr = the row's logits, dr = where its gradient goes (may be the same memory)
 template <class PZ, class PD>
 __device__ __forceinline__ void mtce_row(PZ zr, PD dr, const int32_t* __restrict__ off, int T, const int64_t* __restrict__ labels,
-                                         int64_t n_rows, int64_t row, int sub, float eps, int64_t ignore, float* __restrict__ row_loss) {
+                                         int64_t n_rows, int64_t row, int sub, float eps, int64_t ignore, float* __restrict__ row_loss,
+                                         const float* __restrict__ scale) {
   for (int t = 0; t < T; ++t) {
     const int a = off[t], b = off[t + 1];
     const int C = b - a;
@@ -71,7 +72,9 @@ __device__ __forceinline__ void mtce_row(PZ zr, PD dr, const int32_t* __restrict
     // loss and gradient become NaN (loud in the total and in every gradient downstream) and nothing is read out of range.
     const bool bad = valid && (y_raw < 0 || y_raw >= C);
     const int64_t y = bad ? 0 : y_raw;
-    const float sc = valid ? (bad ? NAN : 1.f) : 0.f;   // per-task 1/count and the incoming gradient are applied by k_mtce_scale
+    // scale == nullptr: per-task 1/count and the incoming gradient are applied later (k_mtce_scale / k_train_loss_bwd);
+    // otherwise scale[t] is the task's final factor (k_task_scale) and the gradient leaves this kernel finished
+    const float sc = valid ? (bad ? NAN : (scale != nullptr ? scale[t] : 1.f)) : 0.f;
     float loss;
     const int nk = (C + 15) >> 4;
     if (nk == 1) task_regs<1>(zr, dr, a, b, sub, y, valid, sc, eps, loss);
@@ -105,11 +108,11 @@ __device__ __forceinline__ void mtce_row(PZ zr, PD dr, const int32_t* __restrict
 
 __global__ __launch_bounds__(256) void k_mtce(const float* __restrict__ z, int64_t ld, const int32_t* __restrict__ off, int T,
                                               const int64_t* __restrict__ labels, int64_t n_rows, float eps, int64_t ignore,
-                                              float* __restrict__ row_loss, float* __restrict__ dz) {
+                                              float* __restrict__ row_loss, float* __restrict__ dz, const float* __restrict__ scale) {
   const int lane = threadIdx.x & 63, sub = lane & 15;
   const int64_t row = (static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
   if (row >= n_rows) return;                                // whole 16-lane rows drop out; DPP never crosses a row
-  mtce_row(z + row * ld, dz + row * ld, off, T, labels, n_rows, row, sub, eps, ignore, row_loss);
+  mtce_row(z + row * ld, dz + row * ld, off, T, labels, n_rows, row, sub, eps, ignore, row_loss, scale);
 }
 
 // The same through LDS: the 16 lanes of a row first fetch the WHOLE row (all loads in flight together, 64 contiguous bytes
@@ -121,7 +124,8 @@ constexpr int kMtceMaxCols = 1024;      // LDS image: 4 waves x 4 rows x W float
 
 __global__ __launch_bounds__(256) void k_mtce_lds(const float* __restrict__ z, int64_t ld, const int32_t* __restrict__ off, int T,
                                                   const int64_t* __restrict__ labels, int64_t n_rows, float eps, int64_t ignore,
-                                                  float* __restrict__ row_loss, float* __restrict__ dz) {
+                                                  float* __restrict__ row_loss, float* __restrict__ dz,
+                                                  const float* __restrict__ scale) {
   extern __shared__ float s_rows[];                         // [16 rows][ld]
   const int lane = threadIdx.x & 63, sub = lane & 15;
   const int slot = (threadIdx.x >> 6) * 4 + (lane >> 4);
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256) void k_mtce_lds(const float* __restrict__ z, i
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  mtce_row(sr, sr, off, T, labels, n_rows, row, sub, eps, ignore, row_loss);
+  mtce_row(sr, sr, off, T, labels, n_rows, row, sub, eps, ignore, row_loss, scale);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   if (vec2) {
@@ -166,13 +170,42 @@ __global__ __launch_bounds__(256) void k_mtce_lds(const float* __restrict__ z, i
 }
 
 void launch_mtce(hipStream_t s, const float* logits, int64_t ld, const int32_t* seg_off, int n_tasks, const int64_t* labels, int64_t n_rows,
-                 float eps, int64_t ignore, float* row_loss, float* dlogits) {
+                 float eps, int64_t ignore, float* row_loss, float* dlogits, const float* scale = nullptr) {
   const unsigned blocks = static_cast<unsigned>((n_rows + 15) / 16);   // 4 waves x 4 rows
   if (ld > 0 && ld <= kMtceMaxCols)
     hipLaunchKernelGGL(k_mtce_lds, dim3(blocks), dim3(256), static_cast<size_t>(16) * ld * sizeof(float), s, logits, ld, seg_off, n_tasks,
-                       labels, n_rows, eps, ignore, row_loss, dlogits);
+                       labels, n_rows, eps, ignore, row_loss, dlogits, scale);
   else
-    hipLaunchKernelGGL(k_mtce, dim3(blocks), dim3(256), 0, s, logits, ld, seg_off, n_tasks, labels, n_rows, eps, ignore, row_loss, dlogits);
+    hipLaunchKernelGGL(k_mtce, dim3(blocks), dim3(256), 0, s, logits, ld, seg_off, n_tasks, labels, n_rows, eps, ignore, row_loss, dlogits, scale);
+}
+
+// Before the cross entropy: wscale[t] = ce_scale * w_t / max(count_t, 1), count_t = #{n : labels[t][n] != ignore}, w_t = 0.5 / p_t^2
+// with task weights (1 without) — everything the logits' gradient is scaled by except the incoming scalar.  With it the
+// cross-entropy kernel writes the finished gradient and the backward pass has no launch of its own (the scale pass read and
+// wrote the [N, C] matrix once more, 23 us at C2, on the step's serial stretch between the heads and their backward).
+__global__ __launch_bounds__(1024) void k_task_scale(const int64_t* __restrict__ labels, int64_t n_rows, int64_t ignore,
+                                                    const float* __restrict__ task_param, float ce_scale, float* __restrict__ wscale) {
+  __shared__ int sc[1024];
+  const int t = blockIdx.x;
+  const int64_t* lb = labels + static_cast<int64_t>(t) * n_rows;
+  int c = 0;
+  int64_t i = threadIdx.x;
+  for (; i + 3 * 1024 < n_rows; i += 4 * 1024) {
+    const int64_t l0 = lb[i], l1 = lb[i + 1024], l2 = lb[i + 2048], l3 = lb[i + 3072];
+    c += (l0 != ignore) + (l1 != ignore) + (l2 != ignore) + (l3 != ignore);
+  }
+  for (; i < n_rows; i += 1024) c += lb[i] != ignore ? 1 : 0;
+  sc[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (static_cast<int>(threadIdx.x) < o) sc[threadIdx.x] += sc[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float w = 1.f;
+    if (task_param != nullptr) w = 0.5f / (task_param[t] * task_param[t]);
+    wscale[t] = ce_scale * w * (1.f / static_cast<float>(sc[0] > 0 ? sc[0] : 1));     // the same expression as k_train_loss_reduce's
+  }
 }
 
 // loss[t] = sum_n row_loss[t][n] / max(count_t, 1),  inv_cnt[t] = 1 / max(count_t, 1),  count_t = #{n : labels[t][n] != ignore}.
@@ -237,10 +270,12 @@ __global__ __launch_bounds__(1024) void k_train_loss_reduce(const float* __restr
                                                             int feat_cols, float lam_over_numel, float* __restrict__ fpart,
                                                             unsigned int* __restrict__ ticket, float* __restrict__ total,
                                                             const float* __restrict__ task_param, float ce_scale,
-                                                            float* __restrict__ wscale, float* __restrict__ dparam) {
+                                                            float* __restrict__ wscale, float* __restrict__ dparam,
+                                                            float* __restrict__ dfeat, int64_t ld_dfeat) {
   __shared__ float sl[1024];
   __shared__ int sc[1024];
   __shared__ bool last;
+  const float dcoef = 2.f * lam_over_numel;            // dfeat = d (lambda * mean(feat^2)) / d feat, for an incoming gradient of 1
   const int t = blockIdx.x;
   float a = 0.f;
   int c = 0;
@@ -268,7 +303,7 @@ __global__ __launch_bounds__(1024) void k_train_loss_reduce(const float* __restr
     const int64_t e0 = (t - T) * per;
     int64_t e1 = e0 + per;
     if (e1 > numel) e1 = numel;
-    if (ld_feat == feat_cols) {                       // contiguous: no index arithmetic, four loads in flight
+    if (ld_feat == feat_cols && (dfeat == nullptr || ld_dfeat == feat_cols)) {   // contiguous: no index arithmetic, four loads in flight
       float a4[4] = {0.f, 0.f, 0.f, 0.f};
       int64_t e = e0 + threadIdx.x;
       for (; e + 3 * 1024 < e1; e += 4 * 1024) {
@@ -276,11 +311,13 @@ __global__ __launch_bounds__(1024) void k_train_loss_reduce(const float* __restr
         for (int u = 0; u < 4; ++u) {
           const float v = feat[e + u * 1024];
           a4[u] = fmaf(v, v, a4[u]);
+          if (dfeat != nullptr) dfeat[e + u * 1024] = dcoef * v;
         }
       }
       for (; e < e1; e += 1024) {
         const float v = feat[e];
         a4[0] = fmaf(v, v, a4[0]);
+        if (dfeat != nullptr) dfeat[e] = dcoef * v;
       }
       a = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     } else {
@@ -288,6 +325,7 @@ __global__ __launch_bounds__(1024) void k_train_loss_reduce(const float* __restr
         const int64_t r = e / feat_cols;
         const float v = feat[r * ld_feat + (e - r * feat_cols)];
         a = fmaf(v, v, a);
+        if (dfeat != nullptr) dfeat[r * ld_dfeat + (e - r * feat_cols)] = dcoef * v;
       }
     }
   }
@@ -461,8 +499,35 @@ extern "C" int agnn_train_loss_f32(const float* logits, int64_t ld, const int32_
   float* fpart = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + 256);
   const float lam = feat ? lambda_feat / (static_cast<float>(n_rows) * static_cast<float>(feat_cols)) : 0.f;
   hipLaunchKernelGGL(k_train_loss_reduce, dim3(n_tasks + kFeatBlocks), dim3(1024), 0, s, row_loss, labels, n_rows, ignore_index, n_tasks,
-                     loss, inv_count, feat, ld_feat, feat_cols, lam, fpart, ticket, total, task_param, ce_scale, wscale, dparam);
+                     loss, inv_count, feat, ld_feat, feat_cols, lam, fpart, ticket, total, task_param, ce_scale, wscale, dparam,
+                     static_cast<float*>(nullptr), static_cast<int64_t>(0));
   return check_launch("train_loss/reduce");
+}
+
+extern "C" int agnn_train_loss_final_f32(const float* logits, int64_t ld, const int32_t* seg_off, int32_t n_tasks, const int64_t* labels,
+                                         int64_t n_rows, float label_smoothing, int64_t ignore_index, const float* feat, int64_t ld_feat,
+                                         int32_t feat_cols, float lambda_feat, const float* task_param, float ce_scale, float* row_loss,
+                                         float* dlogits, float* loss, float* inv_count, float* total, float* wscale, float* dparam,
+                                         float* dfeat, int64_t ld_dfeat, void* workspace, size_t workspace_bytes, agnn_stream_t stream_) {
+  using namespace agnn;
+  if (n_rows <= 0 || n_tasks <= 0 || n_tasks > 1024 - kFeatBlocks || ld < 0) return fail(AGNN_EINVAL, "train_loss_final: n_rows=%lld n_tasks=%d", (long long)n_rows, n_tasks);
+  if (!logits || !seg_off || !labels || !row_loss || !dlogits || !loss || !inv_count || !total || !wscale || !workspace) return fail(AGNN_EINVAL, "train_loss_final: null argument");
+  if (label_smoothing < 0.f || label_smoothing >= 1.f) return fail(AGNN_EINVAL, "train_loss_final: label_smoothing=%f", label_smoothing);
+  if (feat && (feat_cols <= 0 || ld_feat < feat_cols)) return fail(AGNN_EINVAL, "train_loss_final: feat_cols=%d ld_feat=%lld", feat_cols, (long long)ld_feat);
+  if (dfeat && (!feat || ld_dfeat < feat_cols)) return fail(AGNN_EINVAL, "train_loss_final: dfeat without feat, or ld_dfeat=%lld", (long long)ld_dfeat);
+  if (workspace_bytes < agnn_train_loss_workspace_bytes() || (reinterpret_cast<uintptr_t>(workspace) & 255u)) return fail(AGNN_ENOMEM, "train_loss_final: workspace too small or not 256-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  hipLaunchKernelGGL(k_task_scale, dim3(n_tasks), dim3(1024), 0, s, labels, n_rows, ignore_index, task_param, ce_scale, wscale);
+  if (int rc = check_launch("train_loss_final/scale")) return rc;
+  launch_mtce(s, logits, ld, seg_off, n_tasks, labels, n_rows, label_smoothing, ignore_index, row_loss, dlogits, wscale);
+  if (int rc = check_launch("train_loss_final/ce")) return rc;
+  unsigned int* ticket = reinterpret_cast<unsigned int*>(workspace);
+  float* fpart = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + 256);
+  const float lam = feat ? lambda_feat / (static_cast<float>(n_rows) * static_cast<float>(feat_cols)) : 0.f;
+  hipLaunchKernelGGL(k_train_loss_reduce, dim3(n_tasks + kFeatBlocks), dim3(1024), 0, s, row_loss, labels, n_rows, ignore_index, n_tasks,
+                     loss, inv_count, feat, ld_feat, feat_cols, lam, fpart, ticket, total, task_param, ce_scale, wscale, dparam,
+                     dfeat, ld_dfeat);
+  return check_launch("train_loss_final/reduce");
 }
 
 extern "C" int agnn_train_loss_bwd_f32(const float* dlogits, int64_t ld, const int32_t* seg_off, int32_t n_tasks, int64_t n_rows,

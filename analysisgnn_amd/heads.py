@@ -357,9 +357,27 @@ def _check_labels(labels: torch.Tensor, T: int, N: int) -> torch.Tensor:
     return labels.contiguous()
 
 
+_UNIT_GRAD: dict = {}
+FINAL_GRADIENTS = True    # A/B switch: False = the round-2 flow (unscaled gradient forward, agnn_train_loss_bwd_f32 backward)
+
+
+def unit_gradient(device) -> torch.Tensor:
+    """THE resident scalar 1.0 of a device: `loss.backward(gradient=heads.unit_gradient(dev))` tells the objective's backward —
+    by identity, without reading the value — that the incoming gradient is one, so the gradients finished in the forward
+    launches are handed on as they are (no launch).  Any other gradient tensor (the fresh ones `loss.backward()` fills, a
+    loss scaled for gradient accumulation) takes the general path: three element-wise multiplies.  Never written to."""
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == "cuda" else 0))
+    t = _UNIT_GRAD.get(key)
+    if t is None:
+        t = _UNIT_GRAD[key] = torch.ones((), dtype=torch.float32, device=dev)
+    return t
+
+
 class _TrainLoss(torch.autograd.Function):
-    """total = ce_scale * sum_t (w_t CE_t + reg_t) + lam * mean(feat^2) (agnn_train_loss_f32: two launches) and its gradient
-    w.r.t. the logits, feat (agnn_train_loss_bwd_f32: one launch) and the task weights p (one tiny multiply)."""
+    """total = ce_scale * sum_t (w_t CE_t + reg_t) + lam * mean(feat^2) and its gradients w.r.t. the logits, feat and the task
+    weights p, all finished by the forward's three launches (agnn_train_loss_final_f32) for an incoming gradient of one; the
+    backward hands them on (`unit_gradient`) or multiplies them by the incoming scalar."""
 
     @staticmethod
     def forward(ctx, logits, labels, offs_t, feat, task_param, eps: float, ignore_index: int, lam: float, ce_scale: float):
@@ -384,13 +402,25 @@ class _TrainLoss(torch.autograd.Function):
         row_loss = torch.empty((T, N), dtype=torch.float32, device=dev)
         out = torch.empty((4 * T + 1,), dtype=torch.float32, device=dev)      # loss[T] | inv_cnt[T] | total | wscale[T] | dparam[T]
         dlogits = torch.empty_like(logits)
-        _lib.check(lib.agnn_train_loss_f32(logits.data_ptr(), logits.stride(0), offs_t.data_ptr(), T, labels.data_ptr(), N, float(eps),
-                                           int(ignore_index), feat.data_ptr(), feat.stride(0), feat.shape[1], float(lam),
-                                           _lib.ptr(tp), float(ce_scale), row_loss.data_ptr(), dlogits.data_ptr(), out.data_ptr(),
-                                           out[T:].data_ptr(), out[2 * T:].data_ptr(), out[2 * T + 1:].data_ptr(),
-                                           out[3 * T + 1:].data_ptr(), wsp, int(lib.agnn_train_loss_workspace_bytes()),
-                                           _lib.stream_ptr(dev)), "agnn_train_loss_f32")
-        ctx.save_for_backward(dlogits, offs_t, out, feat)
+        ctx.final = FINAL_GRADIENTS
+        dfeat = None
+        if ctx.final:
+            dfeat = torch.empty_like(feat) if ctx.needs_input_grad[3] else None
+            _lib.check(lib.agnn_train_loss_final_f32(logits.data_ptr(), logits.stride(0), offs_t.data_ptr(), T, labels.data_ptr(), N, float(eps),
+                                                     int(ignore_index), feat.data_ptr(), feat.stride(0), feat.shape[1], float(lam),
+                                                     _lib.ptr(tp), float(ce_scale), row_loss.data_ptr(), dlogits.data_ptr(), out.data_ptr(),
+                                                     out[T:].data_ptr(), out[2 * T:].data_ptr(), out[2 * T + 1:].data_ptr(),
+                                                     out[3 * T + 1:].data_ptr(), _lib.ptr(dfeat), dfeat.stride(0) if dfeat is not None else 0,
+                                                     wsp, int(lib.agnn_train_loss_workspace_bytes()), _lib.stream_ptr(dev)),
+                       "agnn_train_loss_final_f32")
+        else:
+            _lib.check(lib.agnn_train_loss_f32(logits.data_ptr(), logits.stride(0), offs_t.data_ptr(), T, labels.data_ptr(), N, float(eps),
+                                               int(ignore_index), feat.data_ptr(), feat.stride(0), feat.shape[1], float(lam),
+                                               _lib.ptr(tp), float(ce_scale), row_loss.data_ptr(), dlogits.data_ptr(), out.data_ptr(),
+                                               out[T:].data_ptr(), out[2 * T:].data_ptr(), out[2 * T + 1:].data_ptr(),
+                                               out[3 * T + 1:].data_ptr(), wsp, int(lib.agnn_train_loss_workspace_bytes()),
+                                               _lib.stream_ptr(dev)), "agnn_train_loss_f32")
+        ctx.save_for_backward(dlogits, offs_t, out, feat, *([dfeat] if dfeat is not None else []))
         ctx.lam = float(lam)
         ctx.T = T
         ctx.has_param = task_param is not None
@@ -400,9 +430,20 @@ class _TrainLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _g_parts):
-        dlogits, offs_t, out, feat = ctx.saved_tensors
+        dlogits, offs_t, out, feat, *rest = ctx.saved_tensors
         dev = dlogits.device
         T = ctx.T
+        want_param = ctx.has_param and ctx.needs_input_grad[4]
+        if ctx.final:
+            dfeat = rest[0] if rest else None
+            if dfeat is None and ctx.needs_input_grad[3]:     # (feat did not require a gradient when the forward ran)
+                dfeat = (2.0 * ctx.lam / feat.numel()) * feat
+            dparam = out[3 * T + 1:4 * T + 1] if want_param else None
+            if g.data_ptr() == unit_gradient(dev).data_ptr():           # one, known by identity: the gradients are finished
+                return dlogits, None, None, dfeat, dparam, None, None, None, None
+            g = g.to(torch.float32)
+            return (dlogits * g, None, None, dfeat * g if dfeat is not None else None, dparam * g if dparam is not None else None,
+                    None, None, None, None)
         g = g.to(torch.float32).contiguous()
         dl = torch.empty_like(dlogits)
         dfeat = torch.empty_like(feat) if ctx.needs_input_grad[3] else None
@@ -412,7 +453,7 @@ class _TrainLoss(torch.autograd.Function):
                                                feat.data_ptr(), feat.stride(0), feat.shape[1], ctx.lam, _lib.ptr(dfeat),
                                                dfeat.stride(0) if dfeat is not None else 0, _lib.stream_ptr(dev)),
                    "agnn_train_loss_bwd_f32")
-        dparam = out[3 * T + 1:4 * T + 1] * g if (ctx.has_param and ctx.needs_input_grad[4]) else None
+        dparam = out[3 * T + 1:4 * T + 1] * g if want_param else None
         return dl, None, None, dfeat, dparam, None, None, None, None
 
 

@@ -366,7 +366,8 @@ def main():
     graph.index_cache_enabled = False                               # fresh batch every step: rebuild the CSR
 
     label_mat = I["label_matrix"] if sampler is not None else torch.stack([labels[t] for t in tasks])      # [T, N]
-    one = torch.ones((), dtype=torch.float32, device=dev)
+    from analysisgnn_amd.heads import unit_gradient
+    one = unit_gradient(dev)                                        # THE resident 1.0: the objective's backward then has no launch
 
     from analysisgnn_amd import _lib as _agnn_lib
 

@@ -527,6 +527,18 @@ int agnn_train_loss_f32(const float* logits, int64_t ld, const int32_t* seg_off,
                         int32_t feat_cols, float lambda_feat, const float* task_param, float ce_scale, float* row_loss,
                         float* dlogits, float* loss, float* inv_count, float* total, float* wscale, float* dparam,
                         void* workspace, size_t workspace_bytes, agnn_stream_t stream);
+/* The same objective with the gradients FINISHED in the forward launches (for an incoming gradient of 1, which is what
+ * `total.backward()` passes): wscale[t] is computed first (a count of the task's valid labels: one small launch), the
+ * cross-entropy kernel then writes dlogits[n, c] = wscale[task(c)] * (p - target) directly, and the launch that reduces the
+ * losses also writes dfeat[n, c] = 2 * lambda_feat / (n_rows * feat_cols) * feat[n, c] (dfeat may be NULL).  The backward pass
+ * then has no launch of its own (agnn_train_loss_bwd_f32's scale pass re-read and re-wrote the [N, C] matrix: 23 us at C2 on
+ * the step's serial stretch); a caller with another incoming gradient g multiplies the three gradients by g.  Same
+ * reference lines, outputs, workspace contract and error behaviour as agnn_train_loss_f32; wscale is required here. */
+int agnn_train_loss_final_f32(const float* logits, int64_t ld, const int32_t* seg_off, int32_t n_tasks, const int64_t* labels,
+                              int64_t n_rows, float label_smoothing, int64_t ignore_index, const float* feat, int64_t ld_feat,
+                              int32_t feat_cols, float lambda_feat, const float* task_param, float ce_scale, float* row_loss,
+                              float* dlogits, float* loss, float* inv_count, float* total, float* wscale, float* dparam,
+                              float* dfeat, int64_t ld_dfeat, void* workspace, size_t workspace_bytes, agnn_stream_t stream);
 int agnn_train_loss_bwd_f32(const float* dlogits, int64_t ld, const int32_t* seg_off, int32_t n_tasks, int64_t n_rows,
                             int32_t n_cols, const float* inv_count, const float* g, float* out, int64_t ld_out,
                             const float* feat, int64_t ld_feat, int32_t feat_cols, float lambda_feat, float* dfeat,

@@ -192,6 +192,53 @@ def test_training_loss_matches_torch(N, lam, gscale, extra, wloss):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("wloss", [False, True])
+def test_training_loss_unit_gradient_launches_nothing_backward_and_matches_both_other_paths(wloss):
+    """The forward launches leave the FINISHED gradients (agnn_train_loss_final_f32); `backward(gradient=heads.unit_gradient(dev))`
+    hands them on without a launch.  Bitwise equal to the general path (a fresh ones tensor: three multiplies by 1.0) and to
+    the round-2 flow (unscaled gradient + agnn_train_loss_bwd_f32: the same two-factor products), and no kernel runs in the
+    backward pass (torch profiler)."""
+    from analysisgnn_amd import heads
+    from analysisgnn_amd.heads import training_loss, unit_gradient
+    g = torch.Generator().manual_seed(3)
+    C = list(TASKS.values())
+    T = len(C)
+    offs = [0]
+    for c in C:
+        offs.append(offs[-1] + c)
+    N = 2000
+    logits = (torch.randn(N, offs[-1], generator=g) * 2).to(DEV)
+    feat = torch.randn(N, 128, generator=g).to(DEV)
+    labels = torch.stack([torch.randint(0, c, (N,), generator=g) for c in C])
+    labels[2, ::3] = -1
+    labels = labels.to(DEV)
+    params = (0.5 + torch.rand(T, generator=g) * 1.5).to(DEV) if wloss else None
+
+    def run(final, unit):
+        saved = heads.FINAL_GRADIENTS
+        heads.FINAL_GRADIENTS = final
+        try:
+            lg, fg = logits.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+            pg = params.clone().requires_grad_(True) if wloss else None
+            total, _ = training_loss(lg, offs, labels, fg, 0.1, 0.1, -1, task_params=pg)
+            torch.cuda.synchronize()
+            with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+                total.backward(gradient=unit_gradient(DEV)) if unit else total.backward()
+                torch.cuda.synchronize()
+            kernels = [e.key for e in prof.key_averages() if e.device_type == torch.autograd.DeviceType.CUDA]
+            return total.detach(), lg.grad, fg.grad, (pg.grad if wloss else None), kernels
+        finally:
+            heads.FINAL_GRADIENTS = saved
+    fast = run(True, True)
+    general = run(True, False)
+    old = run(False, True)
+    assert fast[4] == [], f"kernels in the backward pass: {fast[4]}"
+    assert general[4] != [] and old[4] != []
+    for a, b, c in zip(fast[:4], general[:4], old[:4]):
+        if a is not None:
+            assert torch.equal(a, b) and torch.equal(a, c)
+
+
 def test_training_loss_label_checks():
     """Labels of the wrong dtype / shape are refused on the host; a label outside [0, C) that is not ignore_index makes the
     loss NaN instead of being read out of range (torch: device assert)."""
