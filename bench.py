@@ -82,6 +82,8 @@ def parse_args(argv=None):
     ap.add_argument("--items-home", default="auto", choices=["auto", "on", "off"],
                     help="a branch stream's deferred weight-gradient products: with the main chain's flush (on) / on the branch's own (off) / measured (auto)")
     ap.add_argument("--fused-heads", action="store_true", help="A/B only: the head block's forward in one launch (agnn_heads_fwd_f32)")
+    ap.add_argument("--set", action="append", default=[], metavar="MODULE.NAME=VALUE",
+                    help="A/B runs: set a module-level switch of the package, e.g. --set encoders.JOIN_ONE_LAUNCH=False (value: a Python literal)")
     ap.add_argument("--flush-keep", type=float, default=None,
                     help="share of the main flush point's weight-gradient FLOPs that runs there (rest: the sequence branch's flush); default: measured")
     ap.add_argument("--no-yield-gemm", action="store_true", help="A/B only: the graph stack's second layer does not wait for the GRU's inner input projection")
@@ -351,6 +353,14 @@ def main():
     dp.defer_weight_grads(not args.no_defer and (enc in ("hybridgnn", "hgt") or args.defer_all))
     from analysisgnn_amd import encoders as _enc0
     _enc0.SIDE_STREAM_PRIORITY = args.side_priority
+    for kv in args.set:
+        import ast, importlib
+        name, val = kv.split("=", 1)
+        mod, attr = name.rsplit(".", 1)
+        m = importlib.import_module("analysisgnn_amd." + mod)
+        if not hasattr(m, attr):
+            raise SystemExit(f"--set: analysisgnn_amd.{mod} has no switch {attr}")
+        setattr(m, attr, ast.literal_eval(val))
     from analysisgnn_amd import linear as _lin
     if args.fused_heads:
         from analysisgnn_amd import heads as _heads
