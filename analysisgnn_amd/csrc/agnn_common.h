@@ -32,6 +32,11 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 constexpr int kWave = 64;  // gfx950 wavefront
 
 #if defined(__HIPCC__)
+// ReLU that lets a NaN through, as torch.relu does (fmaxf(NaN, 0) is 0: a poisoned row would come out of the forward pass as
+// zeros, with a finite loss, and only show as non-finite GRADIENTS — seen in round 3 when an un-normalised stack overflowed)
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }
+
+
 // Wave-wide reductions on the DPP cross-lane paths (no LDS round trip as with __shfl_xor / ds_bpermute):
 // quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror reduce each 16-lane row; v_readlane joins the 4 rows.
 template <int CTRL>

@@ -142,7 +142,8 @@ __global__ __launch_bounds__(NT) void k_gru_fwd(const float* __restrict__ gi, co
     q[0] = g3[0];
     q[HH] = g3[1];
     q[2 * HH] = g3[2];
-    q[3 * HH] = fmaf(use, g3[3] - 1.f, 1.f);       // the factor itself
+    q[3 * HH] = use != 0.f ? g3[3] : 1.f;          // the factor itself.  A SELECT: without dropout `drop` aliases the output buffer
+                                                    // (uninitialised ahead of the walk), and 0 * NaN is NaN
   };
   // window s = while the unit lanes run phase 2 of step s
   if (loader) {                          // step s + 2's operands -> LDS, step s + 6's requested: four register sets in flight,
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(NT) void k_gru_bwd(const float* __restrict__ dy, co
     const int sp = s_ < T ? s_ : T - 1;
     const int tq = d ? sp + 1 : T - 2 - sp;      // the time step h_{t-1} came from: outside the sequence at its first step
     const float hp = (tq >= 0 && tq < T) ? o.hp : 0.f;
-    q[0] = o.dyv * fmaf(use, o.dr - 1.f, 1.f);   // dy is d(y * drop)
+    q[0] = o.dyv * (use != 0.f ? o.dr : 1.f);    // dy is d(y * drop); a select, not use * (...): the stand-in operand is not a factor
     q[HH] = o.r;
     q[2 * HH] = o.z;
     q[3 * HH] = o.n;

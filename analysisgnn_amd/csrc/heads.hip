@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void k_heads_fwd(HeadsFwd g, int first_bloc
       for (int s = 0; s < 8; ++s) {
         const float4 zv = *reinterpret_cast<const float4*>(zp + 4 * s);
         if (row_live) *reinterpret_cast<float4*>(zo + 4 * s) = zv;                 // the pre-activation: the backward pass's ReLU mask
-        ya[s] = make_float4(fmaxf(zv.x, 0.f), fmaxf(zv.y, 0.f), fmaxf(zv.z, 0.f), fmaxf(zv.w, 0.f));
+        ya[s] = make_float4(agnn::relu_nan(zv.x), agnn::relu_nan(zv.y), agnn::relu_nan(zv.z), agnn::relu_nan(zv.w));
         sum += (ya[s].x + ya[s].y) + (ya[s].z + ya[s].w);
         if (s & 1) __builtin_amdgcn_sched_barrier(0);
       }

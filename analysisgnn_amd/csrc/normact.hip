@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_na_fwd(NaArgs a, float* __restrict__ y,
   for (int c = 0; c < CH; ++c) {
     on[c] = (c * 256 + lane * 4) < a.H;
     v[c] = on[c] ? xp[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (pre) { v[c].x = fmaxf(v[c].x, 0.f); v[c].y = fmaxf(v[c].y, 0.f); v[c].z = fmaxf(v[c].z, 0.f); v[c].w = fmaxf(v[c].w, 0.f); }
+    if (pre) { v[c].x = agnn::relu_nan(v[c].x); v[c].y = agnn::relu_nan(v[c].y); v[c].z = agnn::relu_nan(v[c].z); v[c].w = agnn::relu_nan(v[c].w); }
     s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
   }
   // statistics: one segment = the whole row (plain LayerNorm) or `seg` floats held by seg/4 adjacent lanes of one chunk
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_na_fwd(NaArgs a, float* __restrict__ y,
     const float4 g = reinterpret_cast<const float4*>(a.gamma)[c * 64 + lane], b = reinterpret_cast<const float4*>(a.beta)[c * 64 + lane];
     float4 o = make_float4((v[c].x - mean[c]) * rstd[c] * g.x + b.x, (v[c].y - mean[c]) * rstd[c] * g.y + b.y,
                            (v[c].z - mean[c]) * rstd[c] * g.z + b.z, (v[c].w - mean[c]) * rstd[c] * g.w + b.w);
-    if (post) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    if (post) { o.x = agnn::relu_nan(o.x); o.y = agnn::relu_nan(o.y); o.z = agnn::relu_nan(o.z); o.w = agnn::relu_nan(o.w); }
     if (drop) {
       const float4 m = keep_mask(a, row, c * 64 + lane, scale);
       o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void k_na_bwd(NaArgs a, const float* __restric
       xr[c] = on[c] ? xp[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
       float4 g = on[c] ? gp[c * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
       float4 v = xr[c];
-      if (pre) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (pre) { v.x = agnn::relu_nan(v.x); v.y = agnn::relu_nan(v.y); v.z = agnn::relu_nan(v.z); v.w = agnn::relu_nan(v.w); }
       xh[c] = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
       if (!on[c]) xh[c] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (drop) {
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void k_mix_fwd(MixArgs a, float* __restrict__ 
       const float4 xv = xp[c * 64 + lane];
       y = make_float4(fmaf(al, y.x - xv.x, xv.x), fmaf(al, y.y - xv.y, xv.y), fmaf(al, y.z - xv.z, xv.z), fmaf(al, y.w - xv.w, xv.w));
     }
-    if (relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+    if (relu) { y.x = agnn::relu_nan(y.x); y.y = agnn::relu_nan(y.y); y.z = agnn::relu_nan(y.z); y.w = agnn::relu_nan(y.w); }
     if (drop) {
       const float4 m = keep_mask(a, row, c * 64 + lane, scale);
       y.x *= m.x; y.y *= m.y; y.z *= m.z; y.w *= m.w;

@@ -6,6 +6,7 @@ incoming relations, weighted sum, and their gradients) runs on the C-ABI kernels
 transforms are library GEMMs.  Build-spec notes (parity unpinned vs graphmuse): encoders.py header."""
 from __future__ import annotations
 
+import contextlib
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -237,6 +238,16 @@ class _BlockDiagWeight(torch.autograd.Function):
 RELT_D = 64           # the head width the relation-transform kernels are built for (csrc/relt.hip)
 RELT_ENABLED = True   # A/B switch: False = round 1's dense GEMM against a block-diagonal weight
 CORE_ENABLED = True   # A/B switch: False = one autograd node per relation / destination type (round 1's graph)
+TYPE_STREAMS = True   # A/B switch (bench.py --set hgt.TYPE_STREAMS=False): the small node types' projections on a second stream
+_TYPE_STREAM: dict = {}
+
+
+def _type_stream(dev) -> "torch.cuda.Stream":
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    s = _TYPE_STREAM.get(idx)
+    if s is None:
+        s = _TYPE_STREAM[idx] = torch.cuda.Stream(device=dev)
+    return s
 
 
 class _RelTransform(torch.autograd.Function):
@@ -662,11 +673,32 @@ class HGTConv(nn.Module):
         heads, H = self.heads, self.out_channels
         D = H // heads
         types = list(x_dict.keys())
+        dev = x_dict[types[0]].device
+        # The node types' projections are independent of each other, and every type but the largest is small (C3: 16 000 notes,
+        # ~2 600 beats, ~700 measures): their kernels are launch-latency bound and, in one stream, sat between the note type's
+        # — 130 us per layer of the stack's serial chain.  They run on a second stream beside the note type's kernels.
+        big = max(types, key=lambda t: n_of[t])
+        two = TYPE_STREAMS and dev.type == "cuda" and len(types) > 1
+        main = torch.cuda.current_stream(dev) if two else None
+        side = _type_stream(dev) if two else None
+
+        def where(t):
+            return torch.cuda.stream(side) if (two and t != big) else contextlib.nullcontext()
+        if two:
+            side.wait_stream(main)
         kqv = []
         for t in types:
             lin = self.kqv_lin.lins[t]
             x = x_dict[t]
-            kqv.append(linear(x if n_of[t] >= x.shape[0] else x[:n_of[t]], lin.weight, lin.bias))
+            with where(t):
+                if two and t != big:
+                    x.record_stream(side)
+                kqv.append(linear(x if n_of[t] >= x.shape[0] else x[:n_of[t]], lin.weight, lin.bias))
+        if two:
+            main.wait_stream(side)
+            for t, y in zip(types, kqv):
+                if t != big:
+                    y.record_stream(main)
         src_rels: Dict[str, List[int]] = {}
         dst_rels: Dict[str, List[Tuple[int, EdgeType]]] = {}
         for e_idx, et in enumerate(self.edge_types):
@@ -679,14 +711,24 @@ class HGTConv(nn.Module):
         p_all = cat_rows([self.p_rel["__".join(e)] for e in self.edge_types])       # [n_edge_types, heads]
         ms = _HGTCore.apply(plan, self.k_rel.weight, self.v_rel.weight, p_all, *kqv)
         out = {}
+        if two:
+            side.wait_stream(main)
         for t, m in zip(types, ms):
             x, n = x_dict[t], n_of[t]
             lo = self.out_lin.lins[t]
-            o = linear(F.gelu(m), lo.weight, lo.bias)
-            # skip connection (+ the ReLU / dropout the stack puts between layers, when it hands them in): one launch each way
-            relu, p, training = post if post is not None else (False, 0.0, False)
-            xs = (x if n >= x.shape[0] else x[:n]) if o.shape[-1] == x.shape[-1] else None
-            out[t] = skip_act(o, xs, self.skip[t] if xs is not None else None, relu, p, training)
+            with where(t):
+                if two and t != big:
+                    m.record_stream(side)
+                o = linear(F.gelu(m), lo.weight, lo.bias)
+                # skip connection (+ the ReLU / dropout the stack puts between layers, when it hands them in): one launch each way
+                relu, p, training = post if post is not None else (False, 0.0, False)
+                xs = (x if n >= x.shape[0] else x[:n]) if o.shape[-1] == x.shape[-1] else None
+                out[t] = skip_act(o, xs, self.skip[t] if xs is not None else None, relu, p, training)
+        if two:
+            main.wait_stream(side)
+            for t in types:
+                if t != big:
+                    out[t].record_stream(main)
         return out
 
 

@@ -84,6 +84,7 @@ def parse_args(argv=None):
     ap.add_argument("--fused-heads", action="store_true", help="A/B only: the head block's forward in one launch (agnn_heads_fwd_f32)")
     ap.add_argument("--set", action="append", default=[], metavar="MODULE.NAME=VALUE",
                     help="A/B runs: set a module-level switch of the package, e.g. --set encoders.JOIN_ONE_LAUNCH=False (value: a Python literal)")
+    ap.add_argument("--lr", type=float, default=5e-4, help="AdamW rate of the run (the reference's warm-up schedule at step 50 of 500: 5e-3 * 50 / 500)")
     ap.add_argument("--flush-keep", type=float, default=None,
                     help="share of the main flush point's weight-gradient FLOPs that runs there (rest: the sequence branch's flush); default: measured")
     ap.add_argument("--no-yield-gemm", action="store_true", help="A/B only: the graph stack's second layer does not wait for the GRU's inner input projection")
@@ -372,7 +373,11 @@ def main():
         _lin.FLUSH_KEEP = args.flush_keep
     if args.items_home != "auto":
         _lin.ITEMS_HOME = args.items_home == "on"
-    opt = dp.FlatAdamW(params, flat, lr=5e-3, weight_decay=5e-3)     # analysis.py:1380-1381 hyper-parameters
+    # analysis.py:1380-1381 + train_analysisgnn.py:58-59: AdamW(lr 5e-3, weight decay 5e-3) behind a LINEAR WARM-UP over the first
+    # 500 steps (analysis.py:1390-1399).  A bench run is the first ~50 steps of that schedule, where the reference's rate is
+    # <= 5e-4; the step's launches take their rate as a constant, so the run uses that value.  (At the peak rate from step 0, on
+    # random labels, the un-normalised HGT stack's activations grow ~40 x per layer within 25 steps and overflow fp32: round 3.)
+    opt = dp.FlatAdamW(params, flat, lr=args.lr, weight_decay=5e-3)
     graph.index_cache_enabled = False                               # fresh batch every step: rebuild the CSR
 
     label_mat = I["label_matrix"] if sampler is not None else torch.stack([labels[t] for t in tasks])      # [T, N]
@@ -394,7 +399,7 @@ def main():
         logits, offs, _ = model.forward_clf_fused(x)
         loss, _ = training_loss(logits, offs, label_mat, x, 0.1, 0.1, -1, task_params=clf_loss.weights())   # analysis.py:1034-1036, :1072
         _lib_stamp("forward + objective issued (main)")
-        loss.backward(gradient=one)                                # a resident 1.0: no fill launch for the root gradient
+        loss.backward(gradient=one)                                # THE resident 1.0: no fill launch, and the objective's backward launches nothing
         flat.pack("early" if buckets else None)                    # two buckets: backward stopped behind the input layers
         _lib_stamp("step end (gradients gathered)")
         return loss
@@ -540,6 +545,12 @@ def main():
             return loss_ref[0]
         loss = fwd_bwd()
         reduce_between(bwd_tail)
+        if os.environ.get("AGNN_BENCH_TRACE"):                     # debugging (eager runs): the loss and any non-finite gradient, per step
+            torch.cuda.synchronize(dev)
+            bad = [n for n, p in trainable.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
+            print(f"[bench] loss {float(loss.detach()):.5f} non-finite gradients: {bad[:6]}", file=sys.stderr)
+            if bad:
+                raise SystemExit(f"[bench] step with non-finite gradients: {bad}")
         update()
         return loss
 

@@ -217,3 +217,19 @@ def test_fused_clip_adamw_matches_torch():
         assert abs(float(opt.last_norm) - float(total)) <= 1e-4 * float(total)
         for pa, pb in zip(a.parameters(), b.parameters()):
             torch.testing.assert_close(pb, pa, rtol=1e-4, atol=1e-6)
+
+
+def test_relu_lets_a_nan_through_like_torch():
+    """torch.relu(NaN) is NaN; fmaxf(NaN, 0) is 0.  A poisoned row must stay visible in the forward pass (a finite loss with
+    non-finite gradients is what the silent version produced): pre- and post-activation of norm_act, and skip_act's ReLU."""
+    from analysisgnn_amd.fused import norm_act, skip_act
+    ln = torch.nn.LayerNorm(64).to(DEV)
+    x = torch.randn(8, 64, device=DEV)
+    x[3, 5] = float("nan")
+    for pre, post in ((True, False), (False, True)):
+        y = norm_act(x, ln, pre_relu=pre, post_relu=post)
+        assert torch.isnan(y[3]).all() and torch.isfinite(y[[0, 1, 2, 4, 5, 6, 7]]).all()
+    o = torch.randn(8, 64, device=DEV)
+    o[2, 7] = float("nan")
+    z = skip_act(o, torch.randn(8, 64, device=DEV), torch.zeros((), device=DEV), True, 0.0, False)
+    assert torch.isnan(z[2, 7]) and int(torch.isnan(z).sum()) == 1

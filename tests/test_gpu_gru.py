@@ -127,3 +127,33 @@ def test_backward_walk_leaves_previous_states(B, T, hidden):
     _lib.check(lib.agnn_gru_bwd_f32(dy.data_ptr(), y.data_ptr(), saved.data_ptr(), w.data_ptr(), B, T, hidden, dgi2.data_ptr(),
                                     dgh2.data_ptr(), None, None, st), "bwd without hprev")
     assert torch.equal(dgi, dgi2) and torch.equal(dgh, dgh2)
+
+
+@pytest.mark.parametrize("fill", [float("nan"), float("inf"), -1e38])
+@pytest.mark.parametrize("B,T,hidden", [(2, 40, 128), (3, 23, 64)])
+def test_forward_without_dropout_ignores_what_the_output_buffer_held(B, T, hidden, fill):
+    """Without inter-layer dropout the kernels get the output buffer as a stand-in for the dropout-scale operand (its values
+    must not matter).  The loader reads that stand-in AHEAD of the walk, i.e. memory the kernel has not written yet: whatever the
+    allocator left there — NaN, Inf — must not reach the result (it did while the stand-in was neutralised by 0 * x instead of a
+    select: a training run diverged whenever the recycled block held a non-finite value).  Same result, bit for bit, as into a
+    zero-filled buffer; the backward kernel likewise with a poisoned `hprev` / gradient buffers."""
+    from analysisgnn_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    r = lambda *s: torch.randn(*s, generator=g).to(DEV)                                 # noqa: E731
+    gi, w, b = r(B, T, 2, 3 * hidden), r(2, 3 * hidden, hidden) * 0.1, r(2, 3 * hidden)
+    st = _lib.stream_ptr(torch.device(DEV))
+    outs = []
+    for f in (0.0, fill):
+        y = torch.full((B, T, 2 * hidden), f, device=DEV)
+        saved = torch.full((B, T, 2, 4, hidden), f, device=DEV)
+        _lib.check(lib.agnn_gru_fwd_f32(gi.data_ptr(), w.data_ptr(), b.data_ptr(), B, T, hidden, y.data_ptr(), saved.data_ptr(), None, None, st), "fwd")
+        dy = torch.ones(B, T, 2 * hidden, device=DEV)
+        dgi, dgh = torch.full_like(gi, f), torch.full_like(gi, f)
+        hp = torch.full((B, T, 2, hidden), f, device=DEV)
+        _lib.check(lib.agnn_gru_bwd_f32(dy.data_ptr(), y.data_ptr(), saved.data_ptr(), w.data_ptr(), B, T, hidden, dgi.data_ptr(),
+                                        dgh.data_ptr(), None, hp.data_ptr(), st), "bwd")
+        outs.append((y, saved, dgi, dgh, hp))
+    for a, c in zip(*outs):
+        assert torch.isfinite(c).all()
+        assert torch.equal(a, c)

@@ -459,3 +459,54 @@ def test_every_backward_schedule_switch_gives_the_same_gradients(enc):
     finally:
         dp.defer_weight_grads(False)
         graph.index_cache_enabled, encoders.LATE_SEQUENCE_BACKWARD, linear.ITEMS_HOME, linear.FLUSH_KEEP, gru.YIELD_TO_PROJECTIONS = saved
+
+
+@pytest.mark.parametrize("enc", ["hybridgnn", "hgt", "metricalgnn"])
+@pytest.mark.parametrize("defer", [False, True])
+def test_step_never_reads_memory_it_has_not_written(enc, defer):
+    """Every `torch.empty` of the step NaN-filled (torch.utils.deterministic.fill_uninitialized_memory): loss and gradients
+    must come out finite and bit for bit what they are on ordinary recycled memory.  A kernel that leaves part of its output
+    unwritten, or neutralises a stand-in operand by `0 * x`, passes every parity test until the allocator hands it a block
+    that holds a NaN (round 3: the recurrence kernels' dropout-scale stand-in)."""
+    from analysisgnn_amd import dp, graph
+    from analysisgnn_amd.heads import MultiTaskLoss, training_loss, unit_gradient
+    from analysisgnn_amd.models import TorchAnalysisGNN
+    from analysisgnn_amd.synth import make_batch, torch_inputs
+    dev = torch.device("cuda", 0)
+    tasks = {"cadence": 4, "localkey": 50, "hrythm": 2}
+    hetero = enc != "hybridgnn"
+    g = make_batch(6, 400, first_seed=3, add_beats=hetero, add_measures=hetero)
+    I = torch_inputs(g, 25, dev, seed=0)
+    labels = torch.stack([torch.randint(0, c, (I["batch_size"],), generator=torch.Generator().manual_seed(i)).to(dev)
+                          for i, c in enumerate(tasks.values())])
+    torch.manual_seed(0)
+    model = TorchAnalysisGNN(g.metadata(), 25, 256, 128, tasks, 3, dropout=0.0, use_jk=False, logit_fusion=False, encoder_type=enc).to(dev).train()
+    clf = MultiTaskLoss(list(tasks)).to(dev)
+    mods = torch.nn.ModuleDict({"m": model, "c": clf})
+    flat = dp.FlatGradBuffer(mods.parameters(), views=False)
+    saved = (graph.index_cache_enabled, torch.are_deterministic_algorithms_enabled(), torch.is_deterministic_algorithms_warn_only_enabled(),
+             torch.utils.deterministic.fill_uninitialized_memory)
+    graph.index_cache_enabled = False
+
+    def fwd_bwd():
+        flat.zero()
+        x = model.encode(I["pitch_spelling"], I["key_signature"], I["x_dict"], I["edge_index_dict"], I["batch_dict"], I["batch_size"],
+                         I["neighbor_mask_node"], I["neighbor_mask_edge"])
+        logits, offs, _ = model.forward_clf_fused(x)
+        loss, _ = training_loss(logits, offs, labels, x, 0.1, 0.1, -1, task_params=clf.weights())
+        loss.backward(gradient=unit_gradient(dev))
+        flat.pack()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), flat.flat.clone()
+    try:
+        dp.defer_weight_grads(defer)
+        l0, g0 = fwd_bwd()
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        torch.utils.deterministic.fill_uninitialized_memory = True
+        l1, g1 = fwd_bwd()
+        assert torch.isfinite(l1) and torch.isfinite(g1).all()
+        assert torch.equal(l0, l1) and torch.equal(g0, g1)
+    finally:
+        dp.defer_weight_grads(False)
+        torch.use_deterministic_algorithms(saved[1], warn_only=saved[2])
+        graph.index_cache_enabled, torch.utils.deterministic.fill_uninitialized_memory = saved[0], saved[3]
