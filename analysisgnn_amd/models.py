@@ -9,6 +9,7 @@ from typing import Dict, Optional
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import _lib, ops
 from .encoders import HybridGNN, MetricalGNN
@@ -132,6 +133,12 @@ class TorchAnalysisGNN(nn.Module):
         # analysis.py:574 — one launch; rows padded to 16 bytes (the spare columns are zero and stay out of the view)
         z_dict["note"] = embed_cat(z_dict["note"], [pitch_spelling, key_signature],
                                    [self.pitch_embedding.weight, self.key_embedding.weight])
+        for k, z in z_dict.items():
+            # an odd input width with unpadded rows (the 25 beat / measure features): one spare zero column behind the last one, out of
+            # the view — the first projection's weight gradient then runs on the MFMA kernel and can be deferred with the others
+            # (as a library product on the step's tail it took 38 + 70 us for 3 688 rows: dW with K = N, and a column sum)
+            if k != "note" and z.is_cuda and z.dim() == 2 and (z.shape[1] & 1) and z.stride(1) == 1 and z.stride(0) == z.shape[1] and z.shape[0] > 0:
+                z_dict[k] = F.pad(z, (0, 1))[:, :z.shape[1]]
         h_dict = {k: self.project_dict[k](z_dict[k]) for k in self.project_dict.keys()}
         self._cut = None
         if self.split_backward and torch.is_grad_enabled():
