@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k_pack(PackTable t) {
     for (int u = 0; u < kElemsPerBlock / 1024; ++u) {
       const int64_t e = (base >> 2) + u * 256 + threadIdx.x;          // float4 index
       if (e >= (total >> 2)) break;
-      const int64_t r = e / c4;
+      const int64_t r = static_cast<uint32_t>(e) / static_cast<uint32_t>(c4);       // 32-bit: an item has < 2^31 elements (host-checked)
       const int c = static_cast<int>(e - r * c4) * 4;
       float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
       if (it.n_src > 0) s = *reinterpret_cast<const float4*>(it.src[0] + r * it.ld_src + c);
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_pack(PackTable t) {
     for (int u = 0; u < kElemsPerBlock / 256; ++u) {
       const int64_t e = base + u * 256 + threadIdx.x;
       if (e >= total) break;
-      const int64_t r = e / it.cols;
+      const int64_t r = static_cast<uint32_t>(e) / static_cast<uint32_t>(it.cols);
       const int c = static_cast<int>(e - r * it.cols);
       float s = it.n_src > 0 ? it.src[0][r * it.ld_src + c] : 0.f;
       for (int k = 1; k < it.n_src; ++k) s += it.src[k][r * it.ld_src + c];
@@ -71,6 +71,7 @@ extern "C" int agnn_pack_f32(int32_t n_items, const agnn_pack_item_t* items, agn
       if (it.rows < 0 || it.cols < 0 || it.n_src < 0 || it.n_src > AGNN_PACK_MAX_SRC)
         return fail(AGNN_EINVAL, "pack: item %d has rows=%d cols=%d n_src=%d", i, it.rows, it.cols, it.n_src);
       if (it.rows == 0 || it.cols == 0) continue;
+      if (static_cast<int64_t>(it.rows) * it.cols >= (int64_t{1} << 31)) return fail(AGNN_EINVAL, "pack: item %d has 2^31 or more elements", i);
       if (!it.dst || it.ld_dst < it.cols || (it.n_src > 0 && it.ld_src < it.cols)) return fail(AGNN_EINVAL, "pack: item %d: null dst or ld < cols", i);
       if (it.n_src == 0) it.ld_src = it.ld_dst;
       bool v = aligned16(it.dst) && (it.ld_dst & 3) == 0 && (it.ld_src & 3) == 0;
