@@ -454,6 +454,24 @@ def weight_grad_batch(items) -> None:
         run(group)
 
 
+HAND_GEMM = True         # the forward projections on the hand-written fp32-MFMA kernel (csrc/gemm.hip, agnn_gemm_nt_f32); False (bench.py --set linear.HAND_GEMM=False): the library
+HAND_GEMM_MIN_ROWS = 4096
+
+
+def _hand_gemm_ok(x, w, b) -> bool:
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and w.dtype == torch.float32 and x.shape[0] >= HAND_GEMM_MIN_ROWS
+            and w.shape[0] % 64 == 0 and x.shape[1] % 16 == 0 and x.stride(1) == 1 and w.stride(1) == 1 and x.stride(0) % 4 == 0
+            and w.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and (b is None or (b.dtype == torch.float32 and b.is_contiguous())))
+
+
+def hand_gemm(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    """x W^T (+ b) on the hand-written fp32-MFMA kernel (csrc/gemm.hip); operands as `_hand_gemm_ok` checks."""
+    y = torch.empty((x.shape[0], w.shape[0]), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().agnn_gemm_nt_f32(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), _lib.ptr(b), x.shape[0], w.shape[0], x.shape[1],
+                                            y.data_ptr(), y.stride(0), _lib.stream_ptr(x.device)), "agnn_gemm_nt_f32")
+    return y
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, acc, pre=None):
@@ -470,6 +488,8 @@ class _LinearFn(torch.autograd.Function):
         if acc is not None:                       # y = acc + x W^T (+ b): the GEMM's beta = 1 epilogue, no separate add
             y = torch.addmm(acc, x, w.t())
             return y + b if b is not None else y
+        if HAND_GEMM and _hand_gemm_ok(x, w, b):
+            return hand_gemm(x, w, b)
         return torch.addmm(b, x, w.t()) if b is not None else x @ w.t()
 
     @staticmethod

@@ -322,6 +322,39 @@ def test_gemm_nt_matches_float64(M, N, K, bias):
     assert lib.agnn_gemm_nt_f32(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), None, M, N + 1, K, c.data_ptr(), c.stride(0), None) < 0
 
 
+@pytest.mark.parametrize("M,N,K,bias", [(5000, 256, 256, True), (4096, 64, 16, False), (16000, 1344, 128, True), (6001, 512, 2048, True), (4500, 192, 80, True)])
+def test_linear_forward_on_the_hand_written_gemm(M, N, K, bias):
+    """linear.linear() with HAND_GEMM (the default): forward on agnn_gemm_nt_f32 — 64-wide column tiles when 128-wide ones would
+    leave fewer than two workgroups per CU, odd K-step counts (K = 80: five steps of 16), a strided input — against float64 and against
+    the library path; the backward pass (library dX, MFMA dW) is the same either way."""
+    from analysisgnn_amd import linear as L
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(M + N + K)
+    x_full = torch.randn(M, K + 4, generator=g).to(dev)
+    x = x_full[:, :K].requires_grad_(True)
+    w = (torch.randn(N, K, generator=g) * 0.1).to(dev).requires_grad_(True)
+    b = torch.randn(N, generator=g).to(dev).requires_grad_(True) if bias else None
+    assert L.HAND_GEMM and L._hand_gemm_ok(x, w, b)
+    saved = L.HAND_GEMM
+    try:
+        outs = []
+        for hand in (True, False):
+            L.HAND_GEMM = hand
+            for t in (x, w, b):
+                if t is not None:
+                    t.grad = None
+            y = L.linear(x, w, b)
+            y.sum().backward()
+            outs.append((y.detach(), x.grad.clone(), w.grad.clone()))
+    finally:
+        L.HAND_GEMM = saved
+    ref = x.detach().double() @ w.detach().double().t() + (b.detach().double() if bias else 0.0)
+    scale = float(ref.abs().max())
+    assert float((outs[0][0].double() - ref).abs().max()) / scale < 5e-6
+    assert float((outs[1][0].double() - ref).abs().max()) / scale < 5e-6
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
 def test_pack_zero_fills_pieces_without_sources():
     """agnn_pack_f32: an item with n_src = 0 clears its destination piece (strided column blocks included) and leaves the rest alone."""
     from analysisgnn_amd.params import pack
