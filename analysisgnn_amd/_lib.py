@@ -142,6 +142,8 @@ SIGNATURES = {
     "agnn_wgrad_batch_f32": (C.c_int, [C.c_int32, C.POINTER(WgradItem), C.c_void_p, C.c_size_t, C.c_void_p]),
     "agnn_gemm_nt_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_int64, C.c_void_p]),
+    "agnn_gemm_nn_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
+                                   C.c_int64, C.c_void_p]),
     "agnn_absdiff_fwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
                                        C.c_void_p]),
     "agnn_absdiff_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,

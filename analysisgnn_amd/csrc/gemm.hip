@@ -39,11 +39,15 @@ struct GemmArgs {
 // BN = 128: a wave owns 64 x 64 (four accumulators); BN = 64: 64 x 32 (two) — twice the workgroups, for shapes whose 128 x 128 tiling
 // gives one workgroup per CU (M = 16 000, N = 256: 250 tiles): a SIMD with ONE wave has nobody to issue MFMAs while that wave waits
 // for its LDS fragments, the barrier or the staging stores
-template <int BN>
+// NN = true: the second operand is K-MAJOR, w[K, N] (C = A w + b) — the input-gradient product dX = dY W with the weight as it
+// lies in memory.  Its tile sits in LDS as it is read, [k][n] (row stride BN + 8: the two lane halves, 4 k rows apart, fall into
+// different bank halves), and a lane's four k values of a fragment come from four 4-byte reads (32 consecutive n per half: no conflict)
+template <int BN, bool NN>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt(GemmArgs g) {
   constexpr int NJ = BN / 64;              // 32-column accumulators per wave
+  constexpr int LDN = BN + 8;
   __shared__ __attribute__((aligned(16))) float sA[2][BM * LDT];
-  __shared__ __attribute__((aligned(16))) float sB[2][BN * LDT];
+  __shared__ __attribute__((aligned(16))) float sB[2][NN ? BK * LDN : BN * LDT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware tile order: consecutive block ids go round-robin over the 8 XCDs; ids b, b + 8, ... (one XCD) take the N tiles
@@ -58,9 +62,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(GemmArgs g) {
   const int sr = tid >> 2, sk = 4 * (tid & 3);
   const float* pa0 = g.a + static_cast<int64_t>(min(row0 + sr, g.M - 1)) * g.ld_a + sk;          // rows past M: clamped, never stored
   const float* pa1 = g.a + static_cast<int64_t>(min(row0 + 64 + sr, g.M - 1)) * g.ld_a + sk;
-  const float* pw0 = g.w + static_cast<int64_t>(col0 + sr) * g.ld_w + sk;
-  const float* pw1 = g.w + static_cast<int64_t>(col0 + (NJ == 2 ? 64 : 0) + sr) * g.ld_w + sk;      // (BN = 64: unused)
   const int so0 = sr * LDT + sk, so1 = (64 + sr) * LDT + sk;
+  // second operand: NT — rows col0 + (t / 4) (+ 64) of w[N, K], as the first; NN — k rows (t / (BN / 4)) (+ 8) of w[K, N], 16 bytes of n each
+  const int nr = NN ? tid / (BN / 4) : 0, nc = NN ? 4 * (tid % (BN / 4)) : 0;
+  const float* pw0 = NN ? g.w + static_cast<int64_t>(nr) * g.ld_w + col0 + nc : g.w + static_cast<int64_t>(col0 + sr) * g.ld_w + sk;
+  const float* pw1 = NN ? g.w + static_cast<int64_t>(nr + (NJ == 2 ? 8 : 0)) * g.ld_w + col0 + nc
+                        : g.w + static_cast<int64_t>(col0 + (NJ == 2 ? 64 : 0) + sr) * g.ld_w + sk;      // (BN = 64: unused)
+  const int sbo0 = NN ? nr * LDN + nc : so0, sbo1 = NN ? (nr + 8) * LDN + nc : so1;
+  const int64_t wmul = NN ? g.ld_w : 1;       // elements between two k of the second operand
 
   f32x16 acc[2][NJ];
 #pragma unroll
@@ -76,21 +85,33 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(GemmArgs g) {
   f32x4 xa0, xa1, xw0, xw1, ya0, ya1, yw0, yw1;
   f32x4 fa0, fa1, fb0, fb1, ga0, ga1, gb0, gb1;
   const int fr = lane & 31, fk = 4 * (lane >> 5);
-  const int fa = (64 * wm + fr) * LDT + fk, fb = (32 * NJ * wn + fr) * LDT + fk;
+  const int fa = (64 * wm + fr) * LDT + fk;
+  const int fb = NN ? fk * LDN + 32 * NJ * wn + fr : (32 * NJ * wn + fr) * LDT + fk;
+  // the four k values (kk + fk .. + 3) of a lane's B fragment, columns fr (+ 32)
+#define BFRAG(BUF, KK, D0, D1)                                                                             \
+  if (NN) {                                                                                                \
+    const float* q_ = &sB[BUF][(KK) * LDN + fb];                                                           \
+    D0 = f32x4{q_[0], q_[LDN], q_[2 * LDN], q_[3 * LDN]};                                                  \
+    D1 = NJ == 2 ? f32x4{q_[32], q_[LDN + 32], q_[2 * LDN + 32], q_[3 * LDN + 32]} : D0;                   \
+  } else {                                                                                                 \
+    D0 = LD4(&sB[BUF][fb + (KK)]);                                                                         \
+    D1 = NJ == 2 ? LD4(&sB[BUF][fb + 32 * LDT + (KK)]) : D0;                                               \
+  }
   const int last = (nk - 1) * BK;
   xa0 = LD4(pa0); xa1 = LD4(pa1); xw0 = LD4(pw0); xw1 = LD4(pw1);
   {
     const int k1 = min(BK, last);
-    ya0 = LD4(pa0 + k1); ya1 = LD4(pa1 + k1); yw0 = LD4(pw0 + k1); yw1 = LD4(pw1 + k1);
+    ya0 = LD4(pa0 + k1); ya1 = LD4(pa1 + k1); yw0 = LD4(pw0 + k1 * wmul); yw1 = LD4(pw1 + k1 * wmul);
   }
-  ST4(&sA[0][so0], xa0); ST4(&sA[0][so1], xa1); ST4(&sB[0][so0], xw0);
-  if (NJ == 2) ST4(&sB[0][so1], xw1);
+  ST4(&sA[0][so0], xa0); ST4(&sA[0][so1], xa1); ST4(&sB[0][sbo0], xw0);
+  if (NJ == 2) ST4(&sB[0][sbo1], xw1);
   {
     const int k2 = min(2 * BK, last);
-    xa0 = LD4(pa0 + k2); xa1 = LD4(pa1 + k2); xw0 = LD4(pw0 + k2); xw1 = LD4(pw1 + k2);
+    xa0 = LD4(pa0 + k2); xa1 = LD4(pa1 + k2); xw0 = LD4(pw0 + k2 * wmul); xw1 = LD4(pw1 + k2 * wmul);
   }
   __syncthreads();
-  fa0 = LD4(&sA[0][fa]); fa1 = LD4(&sA[0][fa + 32 * LDT]); fb0 = LD4(&sB[0][fb]); fb1 = NJ == 2 ? LD4(&sB[0][fb + 32 * LDT]) : fb0;
+  fa0 = LD4(&sA[0][fa]); fa1 = LD4(&sA[0][fa + 32 * LDT]);
+  BFRAG(0, 0, fb0, fb1)
 
 #define MFMA_BLOCK(A0, A1, B0, B1)                                                                         \
   _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                          \
@@ -104,22 +125,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(GemmArgs g) {
   // memory operation — a conditional load costs a full vmcnt drain at the join)
 #define STEP(CUR, KB, SA0, SA1, SW0, SW1)                                                                  \
   {                                                                                                        \
-    ga0 = LD4(&sA[CUR][fa + 8]); ga1 = LD4(&sA[CUR][fa + 32 * LDT + 8]); gb0 = LD4(&sB[CUR][fb + 8]);      \
-    gb1 = NJ == 2 ? LD4(&sB[CUR][fb + 32 * LDT + 8]) : gb0;                                                \
+    ga0 = LD4(&sA[CUR][fa + 8]); ga1 = LD4(&sA[CUR][fa + 32 * LDT + 8]);                                   \
+    BFRAG(CUR, 8, gb0, gb1)                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
     MFMA_BLOCK(fa0, fa1, fb0, fb1)                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
-    ST4(&sA[(CUR) ^ 1][so0], SA0); ST4(&sA[(CUR) ^ 1][so1], SA1); ST4(&sB[(CUR) ^ 1][so0], SW0);           \
-    if (NJ == 2) ST4(&sB[(CUR) ^ 1][so1], SW1);                                                            \
+    ST4(&sA[(CUR) ^ 1][so0], SA0); ST4(&sA[(CUR) ^ 1][so1], SA1); ST4(&sB[(CUR) ^ 1][sbo0], SW0);          \
+    if (NJ == 2) ST4(&sB[(CUR) ^ 1][sbo1], SW1);                                                           \
     {                                                                                                      \
       const int k3 = min(((KB) + 3) * BK, last);                                                           \
-      SA0 = LD4(pa0 + k3); SA1 = LD4(pa1 + k3); SW0 = LD4(pw0 + k3); SW1 = LD4(pw1 + k3);                  \
+      SA0 = LD4(pa0 + k3); SA1 = LD4(pa1 + k3); SW0 = LD4(pw0 + k3 * wmul); SW1 = LD4(pw1 + k3 * wmul);    \
     }                                                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
     MFMA_BLOCK(ga0, ga1, gb0, gb1)                                                                         \
     __syncthreads();                                                                                       \
-    fa0 = LD4(&sA[(CUR) ^ 1][fa]); fa1 = LD4(&sA[(CUR) ^ 1][fa + 32 * LDT]); fb0 = LD4(&sB[(CUR) ^ 1][fb]); \
-    fb1 = NJ == 2 ? LD4(&sB[(CUR) ^ 1][fb + 32 * LDT]) : fb0;                                              \
+    fa0 = LD4(&sA[(CUR) ^ 1][fa]); fa1 = LD4(&sA[(CUR) ^ 1][fa + 32 * LDT]);                               \
+    BFRAG((CUR) ^ 1, 0, fb0, fb1)                                                                          \
   }
   int kb = 0;
   for (; kb + 2 <= nk; kb += 2) {
@@ -128,6 +149,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(GemmArgs g) {
   }
   if (kb < nk) STEP(0, kb, ya0, ya1, yw0, yw1)
 #undef STEP
+#undef BFRAG
 #undef MFMA_BLOCK
 #undef LD4
 #undef ST4
@@ -151,22 +173,40 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(GemmArgs g) {
 
 }  // namespace
 
-extern "C" int agnn_gemm_nt_f32(const float* a, int64_t ld_a, const float* w, int64_t ld_w, const float* bias, int64_t M, int32_t N,
-                                int32_t K, float* c, int64_t ld_c, agnn_stream_t stream_) {
+namespace {
+int launch_gemm(bool nn, const float* a, int64_t ld_a, const float* w, int64_t ld_w, const float* bias, int64_t M, int32_t N, int32_t K,
+                float* c, int64_t ld_c, agnn_stream_t stream_, const char* who) {
   using namespace agnn;
-  if (M < 0 || M >= (int64_t{1} << 31) || N <= 0 || K <= 0) return fail(AGNN_EINVAL, "gemm_nt: bad sizes M=%lld N=%d K=%d", (long long)M, N, K);
-  if ((N % 64) || (K % BK)) return fail(AGNN_EINVAL, "gemm_nt: N=%d must be a multiple of 64 and K=%d of %d", N, K, BK);
+  if (M < 0 || M >= (int64_t{1} << 31) || N <= 0 || K <= 0) return fail(AGNN_EINVAL, "%s: bad sizes M=%lld N=%d K=%d", who, (long long)M, N, K);
+  if ((N % 64) || (K % BK)) return fail(AGNN_EINVAL, "%s: N=%d must be a multiple of 64 and K=%d of %d", who, N, K, BK);
   if (M == 0) return AGNN_OK;
-  if (!a || !w || !c) return fail(AGNN_EINVAL, "gemm_nt: null argument");
-  if (!aligned16(a) || !aligned16(w) || (ld_a & 3) || (ld_w & 3) || ld_a < K || ld_w < K || ld_c < N)
-    return fail(AGNN_EALIGN, "gemm_nt: operands must be 16-byte aligned with leading dimensions that are multiples of 4 and >= K (C: >= N)");
+  if (!a || !w || !c) return fail(AGNN_EINVAL, "%s: null argument", who);
+  if (!aligned16(a) || !aligned16(w) || (ld_a & 3) || (ld_w & 3) || ld_a < K || ld_w < (nn ? N : K) || ld_c < N)
+    return fail(AGNN_EALIGN, "%s: operands must be 16-byte aligned with leading dimensions that are multiples of 4 and cover a row (C: >= N)", who);
   const int64_t tiles_m = (M + BM - 1) / BM;
   const int64_t groups = (tiles_m + 7) / 8;
   // 64-wide column tiles when 128-wide ones would leave the chip with fewer than two workgroups per CU (or N is not a multiple of 128)
   const bool narrow = (N % 128) != 0 || tiles_m * (N / 128) < 512;
   GemmArgs g{a, w, bias, c, ld_a, ld_w, ld_c, static_cast<int32_t>(M), N, K, narrow ? N / 64 : N / 128};
   const dim3 grid(static_cast<unsigned>(groups * 8 * g.tiles_n));
-  if (narrow) hipLaunchKernelGGL(k_gemm_nt<64>, grid, dim3(256), 0, static_cast<hipStream_t>(stream_), g);
-  else hipLaunchKernelGGL(k_gemm_nt<128>, grid, dim3(256), 0, static_cast<hipStream_t>(stream_), g);
-  return check_launch("gemm_nt");
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  if (nn) {
+    if (narrow) hipLaunchKernelGGL((k_gemm_nt<64, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((k_gemm_nt<128, true>), grid, dim3(256), 0, s, g);
+  } else {
+    if (narrow) hipLaunchKernelGGL((k_gemm_nt<64, false>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((k_gemm_nt<128, false>), grid, dim3(256), 0, s, g);
+  }
+  return check_launch(who);
+}
+}  // namespace
+
+extern "C" int agnn_gemm_nt_f32(const float* a, int64_t ld_a, const float* w, int64_t ld_w, const float* bias, int64_t M, int32_t N,
+                                int32_t K, float* c, int64_t ld_c, agnn_stream_t stream_) {
+  return launch_gemm(false, a, ld_a, w, ld_w, bias, M, N, K, c, ld_c, stream_, "gemm_nt");
+}
+
+extern "C" int agnn_gemm_nn_f32(const float* a, int64_t ld_a, const float* w, int64_t ld_w, const float* bias, int64_t M, int32_t N,
+                                int32_t K, float* c, int64_t ld_c, agnn_stream_t stream_) {
+  return launch_gemm(true, a, ld_a, w, ld_w, bias, M, N, K, c, ld_c, stream_, "gemm_nn");
 }

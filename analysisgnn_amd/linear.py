@@ -455,7 +455,15 @@ def weight_grad_batch(items) -> None:
 
 
 HAND_GEMM = True         # the forward projections on the hand-written fp32-MFMA kernel (csrc/gemm.hip, agnn_gemm_nt_f32); False (bench.py --set linear.HAND_GEMM=False): the library
+HAND_GEMM_DX = False     # ... and their input gradients dX = dY W (agnn_gemm_nn_f32: the weight K-major, as it lies).  Off: in the backward
+                         # pass's contended window the TunableOp-chosen library kernels are faster (C2 step 2.87 vs 2.96 ms); bench.py --set linear.HAND_GEMM_DX=True
 HAND_GEMM_MIN_ROWS = 4096
+
+
+def _hand_gemm_dx_ok(dy, w) -> bool:
+    return (dy.is_cuda and dy.dim() == 2 and dy.dtype == torch.float32 and w.dtype == torch.float32 and dy.shape[0] >= HAND_GEMM_MIN_ROWS
+            and w.shape[1] % 64 == 0 and w.shape[0] % 16 == 0 and dy.stride(1) == 1 and w.stride(1) == 1 and dy.stride(0) % 4 == 0
+            and w.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
 
 
 def _hand_gemm_ok(x, w, b) -> bool:
@@ -529,6 +537,10 @@ class _LinearFn(torch.autograd.Function):
                 full = torch.empty((dy.shape[0], x.stride(0)), dtype=dy.dtype, device=dy.device)
                 torch.mm(dy, w[:, c0:c1], out=full[:, c0:c1])
                 dx = full[:, :x.shape[1]]
+            elif HAND_GEMM and HAND_GEMM_DX and _hand_gemm_dx_ok(dy, w):
+                dx = torch.empty((dy.shape[0], w.shape[1]), dtype=torch.float32, device=dy.device)
+                _lib.check(_lib.load().agnn_gemm_nn_f32(dy.data_ptr(), dy.stride(0), w.data_ptr(), w.stride(0), None, dy.shape[0], w.shape[1], w.shape[0],
+                                                        dx.data_ptr(), dx.stride(0), _lib.stream_ptr(dy.device)), "agnn_gemm_nn_f32")
             else:
                 dx = dy @ w
         return dx, dw, db, (dy if ctx.needs_input_grad[3] else None), None

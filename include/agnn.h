@@ -297,9 +297,13 @@ int agnn_gated_bwd_src_f32(const agnn_gated_t* g /* (host) */, const float* ds, 
 /* ------------------------------------------------------------------------------------------
  * fp32 projection GEMM on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32):  C[M, N] = A[M, K] * W[N, K]^T (+ bias[N])
  * — `nn.Linear` / PyG SAGEConv's lin_l, lin_r on a tall activation matrix (ref: models/cadence.py:147-159, core/gnn.py:65,75).
- * Both operands K-contiguous; N % 128 == 0, K % 16 == 0, 16-byte aligned rows (ld % 4 == 0).  The input-gradient product
- * dX = dY * W is the same call with the TRANSPOSED weight as `w` (N := in_features, K := out_features).
+ * agnn_gemm_nt_f32: both operands K-contiguous (the forward product with the weight [out, in] as it lies in memory);
+ * agnn_gemm_nn_f32: the second operand K-MAJOR, w[K, N] — C[M, N] = A[M, K] * w[K, N] (+ bias): the input-gradient product
+ * dX = dY * W with the same weight [out = K, in = N], no transposed copy.  N % 64 == 0, K % 16 == 0, 16-byte aligned rows
+ * (ld % 4 == 0, covering a row of their operand).  linear.HAND_GEMM sends the step's projections with >= 4 096 rows here.
  * ------------------------------------------------------------------------------------------ */
+int agnn_gemm_nn_f32(const float* a, int64_t ld_a, const float* w /* [K, N] */, int64_t ld_w, const float* bias, int64_t M, int32_t N,
+                     int32_t K, float* c, int64_t ld_c, agnn_stream_t stream);
 int agnn_gemm_nt_f32(const float* a, int64_t ld_a, const float* w, int64_t ld_w, const float* bias, int64_t M, int32_t N,
                      int32_t K, float* c, int64_t ld_c, agnn_stream_t stream);
 

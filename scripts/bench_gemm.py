@@ -38,3 +38,19 @@ for M, N, K, what in shapes:
     tl = timed(lambda: torch.addmm(b, a, w.t(), out=out))
     fl = 2.0 * M * N * K
     print(f"{M:6d} {N:5d} {K:5d}  {th:8.1f} {fl / th / 1e6:6.1f}  {tl:8.1f} {fl / tl / 1e6:6.1f}  {err:.1e}  {what}")
+
+print("input-gradient products dX = dY W (agnn_gemm_nn_f32, the weight [out, in] as it lies) against torch.mm:")
+for M, O, I, what in [(16335, 256, 1280, "SAGE layer dX"), (16000, 256, 256, "MLP dX"), (16000, 256, 512, "cat_proj dX"), (16000, 1344, 128, "heads first layer dX"),
+                      (16000, 512, 2048, "C5 SAGE layer dX")]:
+    torch.manual_seed(0)
+    dy = torch.randn(M, O, device=dev); w = torch.randn(O, I, device=dev) * 0.05
+    c = torch.empty(M, I, device=dev)
+    run = lambda: _lib.check(lib.agnn_gemm_nn_f32(dy.data_ptr(), dy.stride(0), w.data_ptr(), w.stride(0), None, M, I, O, c.data_ptr(), c.stride(0), _lib.stream_ptr(dev)), "gemm_nn")
+    run(); torch.cuda.synchronize()
+    ref = dy[:2048].double() @ w.double()
+    err = float((c[:2048].double() - ref).abs().max() / ref.abs().max())
+    th = timed(run)
+    out = torch.empty(M, I, device=dev)
+    tl = timed(lambda: torch.mm(dy, w, out=out))
+    fl = 2.0 * M * O * I
+    print(f"{M:6d} {I:5d} {O:5d}  {th:8.1f} {fl / th / 1e6:6.1f}  {tl:8.1f} {fl / tl / 1e6:6.1f}  {err:.1e}  {what}")

@@ -322,11 +322,30 @@ def test_gemm_nt_matches_float64(M, N, K, bias):
     assert lib.agnn_gemm_nt_f32(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), None, M, N + 1, K, c.data_ptr(), c.stride(0), None) < 0
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 128, 16), (1000, 256, 160), (16335, 1280, 256), (129, 384, 48), (5000, 64, 80), (16000, 128, 1344)])
+def test_gemm_nn_matches_float64(M, N, K):
+    """agnn_gemm_nn_f32: C = A w with the second operand K-major (the input-gradient product dX = dY W on the weight as it lies):
+    against float64, strided operands, row counts that are not tile multiples, odd K-step counts, both tile widths."""
+    from analysisgnn_amd import _lib
+    lib = _lib.load()
+    DEV = "cuda:0"
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K + 8, generator=g).to(DEV)[:, :K]
+    w = (torch.randn(K, N + 4, generator=g) * 0.1).to(DEV)[:, :N]
+    c = torch.full((M, N + 4), 7.0, device=DEV)
+    _lib.check(lib.agnn_gemm_nn_f32(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), None, M, N, K, c.data_ptr(), c.stride(0),
+                                    _lib.stream_ptr(torch.device(DEV))), "agnn_gemm_nn_f32")
+    ref = a.double() @ w.double()
+    assert float((c[:, :N].double() - ref).abs().max() / ref.abs().max()) < 5e-6
+    assert float((c[:, N:] - 7.0).abs().max()) == 0.0
+    assert lib.agnn_gemm_nn_f32(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), None, M, N, K + 1, c.data_ptr(), c.stride(0), None) < 0
+
+
 @pytest.mark.parametrize("M,N,K,bias", [(5000, 256, 256, True), (4096, 64, 16, False), (16000, 1344, 128, True), (6001, 512, 2048, True), (4500, 192, 80, True)])
 def test_linear_forward_on_the_hand_written_gemm(M, N, K, bias):
     """linear.linear() with HAND_GEMM (the default): forward on agnn_gemm_nt_f32 — 64-wide column tiles when 128-wide ones would
     leave fewer than two workgroups per CU, odd K-step counts (K = 80: five steps of 16), a strided input — against float64 and against
-    the library path; the backward pass (library dX, MFMA dW) is the same either way."""
+    the library path; the input gradient runs on agnn_gemm_nn_f32 (library with the switch off), dW on the MFMA weight-gradient kernel either way."""
     from analysisgnn_amd import linear as L
     dev = torch.device("cuda", 0)
     g = torch.Generator().manual_seed(M + N + K)
@@ -335,11 +354,11 @@ def test_linear_forward_on_the_hand_written_gemm(M, N, K, bias):
     w = (torch.randn(N, K, generator=g) * 0.1).to(dev).requires_grad_(True)
     b = torch.randn(N, generator=g).to(dev).requires_grad_(True) if bias else None
     assert L.HAND_GEMM and L._hand_gemm_ok(x, w, b)
-    saved = L.HAND_GEMM
+    saved = (L.HAND_GEMM, L.HAND_GEMM_DX)
     try:
         outs = []
         for hand in (True, False):
-            L.HAND_GEMM = hand
+            L.HAND_GEMM = L.HAND_GEMM_DX = hand
             for t in (x, w, b):
                 if t is not None:
                     t.grad = None
@@ -347,12 +366,15 @@ def test_linear_forward_on_the_hand_written_gemm(M, N, K, bias):
             y.sum().backward()
             outs.append((y.detach(), x.grad.clone(), w.grad.clone()))
     finally:
-        L.HAND_GEMM = saved
+        L.HAND_GEMM, L.HAND_GEMM_DX = saved
     ref = x.detach().double() @ w.detach().double().t() + (b.detach().double() if bias else 0.0)
     scale = float(ref.abs().max())
     assert float((outs[0][0].double() - ref).abs().max()) / scale < 5e-6
     assert float((outs[1][0].double() - ref).abs().max()) / scale < 5e-6
-    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    dx_ref = torch.ones(M, N, dtype=torch.float64, device=dev) @ w.detach().double()        # d(sum y) / dx
+    for o in outs:
+        assert float((o[1].double() - dx_ref).abs().max()) / float(dx_ref.abs().max()) < 5e-6
+    assert torch.equal(outs[0][2], outs[1][2])                 # dW: the MFMA weight-gradient kernel either way
 
 
 def test_pack_zero_fills_pieces_without_sources():
