@@ -458,6 +458,8 @@ HAND_GEMM = True         # the forward projections on the hand-written fp32-MFMA
 HAND_GEMM_DX = False     # ... and their input gradients dX = dY W (agnn_gemm_nn_f32: the weight K-major, as it lies).  Off: in the backward
                          # pass's contended window the TunableOp-chosen library kernels are faster (C2 step 2.87 vs 2.96 ms); bench.py --set linear.HAND_GEMM_DX=True
 HAND_GEMM_MIN_ROWS = 4096
+HAND_GEMM_MIN_K, HAND_GEMM_MIN_N = 256, 256    # shorter K (8 steps: the tile's prologue / epilogue weigh as much as its MFMAs) or 128 columns: the
+                                                # library keeps 15 - 25 % (project_enc's last layers, the heads' first layer: profiles/r03_gemm.md)
 HAND_GEMM_MAX_K = 1536    # beyond it (C5's [16 000, 2 048] x [2 048, 512] layers) the library's 256-wide tiles keep 8 % on this kernel: C5 step 6.24 vs 6.17 ms
 
 
@@ -469,7 +471,7 @@ def _hand_gemm_dx_ok(dy, w) -> bool:
 
 def _hand_gemm_ok(x, w, b) -> bool:
     return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and w.dtype == torch.float32 and x.shape[0] >= HAND_GEMM_MIN_ROWS
-            and x.shape[1] <= HAND_GEMM_MAX_K and w.shape[0] % 64 == 0 and x.shape[1] % 16 == 0 and x.stride(1) == 1 and w.stride(1) == 1 and x.stride(0) % 4 == 0
+            and HAND_GEMM_MIN_K <= x.shape[1] <= HAND_GEMM_MAX_K and w.shape[0] >= HAND_GEMM_MIN_N and w.shape[0] % 64 == 0 and x.shape[1] % 16 == 0 and x.stride(1) == 1 and w.stride(1) == 1 and x.stride(0) % 4 == 0
             and w.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and (b is None or (b.dtype == torch.float32 and b.is_contiguous())))
 
 

@@ -353,9 +353,9 @@ def test_linear_forward_on_the_hand_written_gemm(M, N, K, bias):
     x = x_full[:, :K].requires_grad_(True)
     w = (torch.randn(N, K, generator=g) * 0.1).to(dev).requires_grad_(True)
     b = torch.randn(N, generator=g).to(dev).requires_grad_(True) if bias else None
-    assert L.HAND_GEMM and (K > L.HAND_GEMM_MAX_K or L._hand_gemm_ok(x, w, b))
-    saved = (L.HAND_GEMM, L.HAND_GEMM_DX, L.HAND_GEMM_MAX_K)
-    L.HAND_GEMM_MAX_K = 1 << 20
+    saved = (L.HAND_GEMM, L.HAND_GEMM_DX, L.HAND_GEMM_MAX_K, L.HAND_GEMM_MIN_K, L.HAND_GEMM_MIN_N)
+    L.HAND_GEMM_MAX_K, L.HAND_GEMM_MIN_K, L.HAND_GEMM_MIN_N = 1 << 20, 16, 64          # every shape the kernel takes, not only the ones the step sends it
+    assert L.HAND_GEMM and L._hand_gemm_ok(x, w, b)
     try:
         outs = []
         for hand in (True, False):
@@ -367,7 +367,7 @@ def test_linear_forward_on_the_hand_written_gemm(M, N, K, bias):
             y.sum().backward()
             outs.append((y.detach(), x.grad.clone(), w.grad.clone()))
     finally:
-        L.HAND_GEMM, L.HAND_GEMM_DX, L.HAND_GEMM_MAX_K = saved
+        L.HAND_GEMM, L.HAND_GEMM_DX, L.HAND_GEMM_MAX_K, L.HAND_GEMM_MIN_K, L.HAND_GEMM_MIN_N = saved
     ref = x.detach().double() @ w.detach().double().t() + (b.detach().double() if bias else 0.0)
     scale = float(ref.abs().max())
     assert float((outs[0][0].double() - ref).abs().max()) / scale < 5e-6
