@@ -466,13 +466,13 @@ HAND_GEMM_MAX_K = 1536    # beyond it (C5's [16 000, 2 048] x [2 048, 512] layer
 def _hand_gemm_dx_ok(dy, w) -> bool:
     return (dy.is_cuda and dy.dim() == 2 and dy.dtype == torch.float32 and w.dtype == torch.float32 and dy.shape[0] >= HAND_GEMM_MIN_ROWS
             and w.shape[1] % 64 == 0 and w.shape[0] % 16 == 0 and dy.stride(1) == 1 and w.stride(1) == 1 and dy.stride(0) % 4 == 0
-            and w.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
+            and w.stride(0) % 4 == 0 and dy.stride(0) >= dy.shape[1] and w.stride(0) >= w.shape[1] and dy.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
 
 
 def _hand_gemm_ok(x, w, b) -> bool:
     return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and w.dtype == torch.float32 and x.shape[0] >= HAND_GEMM_MIN_ROWS
             and HAND_GEMM_MIN_K <= x.shape[1] <= HAND_GEMM_MAX_K and w.shape[0] >= HAND_GEMM_MIN_N and w.shape[0] % 64 == 0 and x.shape[1] % 16 == 0 and x.stride(1) == 1 and w.stride(1) == 1 and x.stride(0) % 4 == 0
-            and w.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and (b is None or (b.dtype == torch.float32 and b.is_contiguous())))
+            and w.stride(0) % 4 == 0 and x.stride(0) >= x.shape[1] and w.stride(0) >= w.shape[1] and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and (b is None or (b.dtype == torch.float32 and b.is_contiguous())))
 
 
 def hand_gemm(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:

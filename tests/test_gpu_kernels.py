@@ -378,6 +378,22 @@ def test_linear_forward_on_the_hand_written_gemm(M, N, K, bias):
     assert torch.equal(outs[0][2], outs[1][2])                 # dW: the MFMA weight-gradient kernel either way
 
 
+def test_linear_falls_back_to_the_library_for_operands_the_hand_written_gemm_refuses():
+    """A broadcast (stride-0) input, an unaligned view, K not a multiple of 16: `linear` must take the library path (same result as
+    torch), not hand the kernel an operand it rejects."""
+    from analysisgnn_amd import linear as L
+    dev = torch.device("cuda", 0)
+    w = (torch.randn(256, 256, device=dev) * 0.1)
+    b = torch.randn(256, device=dev)
+    row = torch.randn(1, 256, device=dev)
+    for x in (row.expand(5000, 256), torch.randn(5000, 257, device=dev)[:, 1:], torch.randn(5000, 256, device=dev)):
+        y = L.linear(x, w, b)
+        ref = torch.addmm(b, x, w.t())
+        assert float((y - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    x = torch.randn(5000, 250, device=dev)
+    assert torch.equal(L.linear(x, w[:, :250].contiguous(), b), torch.addmm(b, x, w[:, :250].contiguous().t()))
+
+
 def test_pack_zero_fills_pieces_without_sources():
     """agnn_pack_f32: an item with n_src = 0 clears its destination piece (strided column blocks included) and leaves the rest alone."""
     from analysisgnn_amd.params import pack
