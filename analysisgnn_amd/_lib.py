@@ -57,6 +57,14 @@ class HgtSrcItem(C.Structure):
                 ("col_limit", C.c_int32)]
 
 
+class HgtDstItem(C.Structure):
+    _fields_ = [("rels", C.c_void_p), ("n_rel", C.c_int32), ("q", C.c_void_p), ("ld_q", C.c_int64), ("n_rows", C.c_int64),
+                ("out", C.c_void_p), ("ld_out", C.c_int64), ("m_out", C.c_void_p), ("linv_out", C.c_void_p)]
+
+
+HGT_MAX_DST = 4
+
+
 class HgtRel(C.Structure):
     _fields_ = [("k", C.c_void_p), ("v", C.c_void_p), ("rowptr", C.c_void_p), ("rowend", C.c_void_p),
                 ("col", C.c_void_p), ("perm", C.c_void_p), ("pscale", C.c_void_p), ("ld", C.c_int64),
@@ -114,6 +122,7 @@ SIGNATURES = {
                                      C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32),
                                      C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "agnn_gru_hprev_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "agnn_hgt_attn_fwd_multi_f32": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "agnn_hgt_attn_fwd_f32": (C.c_int, [C.c_int, C.POINTER(HgtRel), C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
                                         C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "agnn_hgt_attn_bwd_dst_f32": (C.c_int, [C.c_int, C.POINTER(HgtRel), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,

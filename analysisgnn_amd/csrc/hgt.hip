@@ -55,11 +55,11 @@ struct HgtArgs {
 };
 
 template <int CH>
-__global__ __launch_bounds__(256) void k_hgt_fwd(HgtTable t, HgtArgs a, float* __restrict__ out, int64_t ld_out,
-                                                 float* __restrict__ m_out, float* __restrict__ linv_out) {
+__device__ __forceinline__ void hgt_fwd_rows(const HgtTable& t, int r0, int r1, const HgtArgs& a, float* __restrict__ out, int64_t ld_out,
+                                             float* __restrict__ m_out, float* __restrict__ linv_out, int block, int n_blocks) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int vb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-contiguous row slabs
+  const int vb = (block & 7) * (n_blocks >> 3) + (block >> 3);   // XCD-contiguous row slabs
   const int row = vb * 4 + wave;
   if (row >= a.n_rows) return;
   const int D = a.H / a.heads;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_hgt_fwd(HgtTable t, HgtArgs a, float* _
   // Index phase on the scalar unit (rowptr / rowend of a relation are wave-uniform), the column ids of a segment in ONE
   // vector register (broadcast with v_readlane), and TWO neighbours in flight: their four K' / V' rows are requested
   // before the first score is reduced, and one running-max update (three exponentials) covers both.
-  for (int r = 0; r < t.n_rel; ++r) {
+  for (int r = r0; r < r1; ++r) {
     const agnn_hgt_rel_t& R = t.r[r];
     const int start = ((hk_i32p)R.rowptr)[row];
     const int end = (R.rowend != nullptr) ? ((hk_i32p)R.rowend)[row] : ((hk_i32p)R.rowptr)[row + 1];
@@ -140,6 +140,34 @@ __global__ __launch_bounds__(256) void k_hgt_fwd(HgtTable t, HgtArgs a, float* _
       linv_out[static_cast<int64_t>(row) * a.heads + head[c]] = linv;
     }
   }
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void k_hgt_fwd(HgtTable t, HgtArgs a, float* __restrict__ out, int64_t ld_out,
+                                                 float* __restrict__ m_out, float* __restrict__ linv_out) {
+  hgt_fwd_rows<CH>(t, 0, t.n_rel, a, out, ld_out, m_out, linv_out, blockIdx.x, gridDim.x);
+}
+
+// Several destination types in ONE launch (an HGT layer has one attention per destination type; the small types' launches —
+// beats, measures — each cost a launch's latency on the layer's serial chain for a few microseconds of work): item i owns the
+// blocks [blk0[i], blk0[i + 1]) and the relations [rel0[i], rel0[i + 1]) of the table.
+struct HgtMulti {
+  HgtArgs a[AGNN_HGT_MAX_DST];
+  float* out[AGNN_HGT_MAX_DST];
+  float* m_out[AGNN_HGT_MAX_DST];
+  float* linv_out[AGNN_HGT_MAX_DST];
+  int64_t ld_out[AGNN_HGT_MAX_DST];
+  int32_t rel0[AGNN_HGT_MAX_DST + 1];
+  int32_t blk0[AGNN_HGT_MAX_DST + 1];
+  int32_t n_items;
+};
+
+template <int CH>
+__global__ __launch_bounds__(256) void k_hgt_fwd_multi(HgtTable t, HgtMulti mm) {
+  int i = 0;
+  while (i + 1 < mm.n_items && static_cast<int>(blockIdx.x) >= mm.blk0[i + 1]) ++i;     // block-uniform
+  hgt_fwd_rows<CH>(t, mm.rel0[i], mm.rel0[i + 1], mm.a[i], mm.out[i], mm.ld_out[i], mm.m_out[i], mm.linv_out[i],
+                   static_cast<int>(blockIdx.x) - mm.blk0[i], mm.blk0[i + 1] - mm.blk0[i]);
 }
 
 // Pass by destination: dq, and per edge (indexed by the edge's COO position `perm`) alpha, gs = ds * pscale,
@@ -376,6 +404,43 @@ extern "C" int agnn_hgt_attn_fwd_f32(int n_rel, const agnn_hgt_rel_t* rels, cons
   else if (H <= 512) hipLaunchKernelGGL(k_hgt_fwd<2>, grid, block, 0, s, t, a, out, ld_out, m_out, linv_out);
   else hipLaunchKernelGGL(k_hgt_fwd<4>, grid, block, 0, s, t, a, out, ld_out, m_out, linv_out);
   return check_launch("hgt_fwd");
+}
+
+extern "C" int agnn_hgt_attn_fwd_multi_f32(int32_t n_items, const agnn_hgt_dst_item_t* items, int32_t H, int32_t heads, agnn_stream_t stream_) {
+  using namespace agnn;
+  if (n_items < 0 || n_items > AGNN_HGT_MAX_DST || (n_items > 0 && !items)) return fail(AGNN_EINVAL, "hgt_fwd_multi: n_items=%d (0 .. %d)", n_items, AGNN_HGT_MAX_DST);
+  HgtTable t{};
+  HgtMulti mm{};
+  int nr = 0, blocks = 0, k = 0;
+  for (int i = 0; i < n_items; ++i) {
+    const agnn_hgt_dst_item_t& it = items[i];
+    if (int rc = check_shape("hgt_fwd_multi", it.n_rows, H, heads)) return rc;
+    if (it.n_rel < 0 || nr + it.n_rel > AGNN_MAX_SEG) return fail(AGNN_EINVAL, "hgt_fwd_multi: %d relations in all (max %d)", nr + it.n_rel, AGNN_MAX_SEG);
+    if (it.n_rows == 0) continue;
+    if (!it.q || !it.out || !it.m_out || !it.linv_out || (it.n_rel > 0 && !it.rels)) return fail(AGNN_EINVAL, "hgt_fwd_multi: item %d: null argument", i);
+    if (!aligned16(it.q) || !aligned16(it.out) || (it.ld_q & 3) || (it.ld_out & 3)) return fail(AGNN_EALIGN, "hgt_fwd_multi: item %d: q/out misaligned", i);
+    mm.rel0[k] = nr;
+    for (int r = 0; r < it.n_rel; ++r) {
+      const agnn_hgt_rel_t& R = it.rels[r];
+      if (!R.rowptr || !R.pscale) return fail(AGNN_EINVAL, "hgt_fwd_multi: item %d relation %d incomplete", i, r);
+      if ((R.k && !aligned16(R.k)) || (R.v && !aligned16(R.v)) || (R.ld & 3)) return fail(AGNN_EALIGN, "hgt_fwd_multi: item %d relation %d k/v misaligned", i, r);
+      t.r[nr++] = R;
+    }
+    mm.a[k] = HgtArgs{it.q, it.ld_q, static_cast<int32_t>(it.n_rows), H, heads, INT32_MAX};
+    mm.out[k] = it.out; mm.m_out[k] = it.m_out; mm.linv_out[k] = it.linv_out; mm.ld_out[k] = it.ld_out;
+    mm.blk0[k] = blocks;
+    blocks += static_cast<int>(grid_for(it.n_rows));
+    ++k;
+  }
+  if (k == 0) return AGNN_OK;
+  mm.rel0[k] = nr; mm.blk0[k] = blocks; mm.n_items = k;
+  t.n_rel = nr;
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+  if (H <= 256) hipLaunchKernelGGL(k_hgt_fwd_multi<1>, grid, block, 0, s, t, mm);
+  else if (H <= 512) hipLaunchKernelGGL(k_hgt_fwd_multi<2>, grid, block, 0, s, t, mm);
+  else hipLaunchKernelGGL(k_hgt_fwd_multi<4>, grid, block, 0, s, t, mm);
+  return check_launch("hgt_fwd_multi");
 }
 
 extern "C" int agnn_hgt_attn_bwd_dst_f32(int n_rel, const agnn_hgt_rel_t* rels, const float* q, int64_t ld_q, const float* dm,

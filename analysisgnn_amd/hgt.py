@@ -238,6 +238,7 @@ class _BlockDiagWeight(torch.autograd.Function):
 RELT_D = 64           # the head width the relation-transform kernels are built for (csrc/relt.hip)
 RELT_ENABLED = True   # A/B switch: False = round 1's dense GEMM against a block-diagonal weight
 CORE_ENABLED = True   # A/B switch: False = one autograd node per relation / destination type (round 1's graph)
+ATTN_ONE_LAUNCH = True  # A/B switch (bench.py --set hgt.ATTN_ONE_LAUNCH=False): the destination types' forward attention in one launch
 TYPE_STREAMS = True   # A/B switch (bench.py --set hgt.TYPE_STREAMS=False): the small node types' projections on a second stream
 _TYPE_STREAM: dict = {}
 
@@ -361,6 +362,11 @@ class _HGTCore(torch.autograd.Function):
                 _lib.check(lib.agnn_relt_fwd_f32(2, items, R, heads, D, N, _lib.stream_ptr(dev)), "agnn_relt_fwd_f32")
         ps = (p_all.detach() * (1.0 / math.sqrt(D))).contiguous()                   # [n_edge_types, heads]
         outs, stats = [], {}
+        live = [t for t in plan.types if plan.dst_rels.get(t) and plan.n_of[t] > 0]
+        one_launch = (ATTN_ONE_LAUNCH and 1 < len(live) <= _lib.HGT_MAX_DST
+                      and sum(len(plan.dst_rels[t]) for t in live) <= _lib.MAX_SEG)
+        items = (_lib.HgtDstItem * max(len(live), 1))()
+        hold = []                                            # relation tables and row-end vectors: alive until the launch is issued
         for t in plan.types:
             n = plan.n_of[t]
             rels = plan.dst_rels.get(t, [])
@@ -372,10 +378,19 @@ class _HGTCore(torch.autograd.Function):
             linv = torch.empty((n, heads), dtype=torch.float32, device=dev)
             arr, keep = _HGTCore._rel_table(plan, rels, kp, vp, ps, H)
             q = X[t]
-            _lib.check(lib.agnn_hgt_attn_fwd_f32(len(rels), arr, q.data_ptr() + 4 * H, q.stride(0), n, H, heads, out.data_ptr(),
-                                                 out.stride(0), m.data_ptr(), linv.data_ptr(), _lib.stream_ptr(dev)), "agnn_hgt_attn_fwd_f32")
+            if one_launch:                               # every destination type's attention in ONE launch (agnn_hgt_attn_fwd_multi_f32)
+                it = items[len(hold)]
+                it.rels, it.n_rel = _lib.C.cast(arr, _lib.C.c_void_p), len(rels)
+                it.q, it.ld_q, it.n_rows = q.data_ptr() + 4 * H, q.stride(0), n
+                it.out, it.ld_out, it.m_out, it.linv_out = out.data_ptr(), out.stride(0), m.data_ptr(), linv.data_ptr()
+                hold.append((arr, keep))
+            else:
+                _lib.check(lib.agnn_hgt_attn_fwd_f32(len(rels), arr, q.data_ptr() + 4 * H, q.stride(0), n, H, heads, out.data_ptr(),
+                                                     out.stride(0), m.data_ptr(), linv.data_ptr(), _lib.stream_ptr(dev)), "agnn_hgt_attn_fwd_f32")
             stats[t] = (m, linv)
             outs.append(out)
+        if one_launch:
+            _lib.check(lib.agnn_hgt_attn_fwd_multi_f32(len(hold), items, H, heads, _lib.stream_ptr(dev)), "agnn_hgt_attn_fwd_multi_f32")
         ctx.plan = plan
         ctx.steal_refs = leaf_refs(wk, wv)             # (their gradients may be produced late: see backward)
         ctx.wg_defer = all(t.is_leaf or getattr(t, "_agnn_wgrad_deferrable", False) for t in (wk, wv))

@@ -238,6 +238,23 @@ typedef struct {
 int agnn_hgt_attn_fwd_f32(int n_rel, const agnn_hgt_rel_t* rels /* (host) */, const float* q, int64_t ld_q,
                           int64_t n_rows, int32_t H, int32_t heads, float* out, int64_t ld_out,
                           float* m_out, float* linv_out, agnn_stream_t stream);
+/* The attention of several DESTINATION types in one launch (an HGT layer has one per destination type; ref. as above): item i =
+ * one agnn_hgt_attn_fwd_f32 call.  Items and their relation tables are read on the host during the call; at most
+ * AGNN_HGT_MAX_DST items, AGNN_MAX_SEG relations in all. */
+#define AGNN_HGT_MAX_DST 4
+typedef struct {
+  const agnn_hgt_rel_t* rels;   /* (host) n_rel relations ending in this destination type */
+  int32_t n_rel;
+  const float* q;
+  int64_t ld_q;
+  int64_t n_rows;
+  float* out;
+  int64_t ld_out;
+  float* m_out;
+  float* linv_out;
+} agnn_hgt_dst_item_t;
+int agnn_hgt_attn_fwd_multi_f32(int32_t n_items, const agnn_hgt_dst_item_t* items /* (host) */, int32_t H, int32_t heads,
+                                agnn_stream_t stream);
 int agnn_hgt_attn_bwd_dst_f32(int n_rel, const agnn_hgt_rel_t* rels /* (host) */, const float* q, int64_t ld_q,
                               const float* dm, int64_t ld_dm, const float* out, int64_t ld_out,
                               const float* m_in, const float* linv_in, int64_t n_rows, int32_t H,

@@ -239,3 +239,31 @@ def test_skip_act_epilogue_matches_torch(n, H, relu, p, with_x):
     if with_x:
         assert_close_rel(xd.grad, x64.grad, 1e-6, "d x")
         assert_close_rel(sd.grad, s64.grad, 1e-5, "d skip")
+
+
+def test_destination_types_in_one_attention_launch_give_the_same_layer():
+    """agnn_hgt_attn_fwd_multi_f32 (every destination type's edge softmax in one launch) against one launch per type: the layer's
+    outputs and input gradients bit for bit (the same rows by the same code), on the graph with note / beat / measure destinations."""
+    from analysisgnn_amd import hgt
+    from analysisgnn_amd.hgt import HGTConv
+    from analysisgnn_amd.synth import torch_inputs
+    g = _graph("metrical_rev")
+    torch.manual_seed(3)
+    m = HGTConv(256, 256, g.metadata(), 4).to(DEV)
+    I = torch_inputs(g, in_channels=256, seed=2)
+    ei = {k: v.to(DEV) for k, v in I["edge_index_dict"].items()}
+    saved = hgt.ATTN_ONE_LAUNCH
+    res = []
+    try:
+        for one in (True, False):
+            hgt.ATTN_ONE_LAUNCH = one
+            xg = {k: v.to(DEV).requires_grad_(True) for k, v in I["x_dict"].items()}
+            out = m(xg, ei)
+            sum(o.square().sum() for o in out.values()).backward()
+            res.append(({k: o.detach() for k, o in out.items()}, {k: x.grad for k, x in xg.items()}))
+    finally:
+        hgt.ATTN_ONE_LAUNCH = saved
+    assert len(res[0][0]) >= 3
+    for k in res[0][0]:
+        assert torch.equal(res[0][0][k], res[1][0][k]), k
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
