@@ -79,6 +79,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-defer", action="store_true", help="A/B only: weight gradients where they are computed, not deferred")
     ap.add_argument("--defer-all", action="store_true", help="A/B only: deferred (batched) weight gradients for MetricalGNN too")
     ap.add_argument("--no-wgrad-overlap", action="store_true", help="A/B only: weight gradients on the main stream")
+    ap.add_argument("--force-wgrad-overlap", action="store_true", help="A/B only: the weight-gradient stream for any workload (default: c2 / c2s)")
     ap.add_argument("--items-home", default="auto", choices=["auto", "on", "off"],
                     help="a branch stream's deferred weight-gradient products: with the main chain's flush (on) / on the branch's own (off) / measured (auto)")
     ap.add_argument("--fused-heads", action="store_true", help="A/B only: the head block's forward in one launch (agnn_heads_fwd_f32)")
@@ -348,7 +349,8 @@ def main():
     # the longer one (C2; with HGT / MetricalGNN the graph branch is, and the extra stream only adds contention)
     # (round 3, measured and not kept: + "embed" — the embedding tables' gradient, the backward pass's last node, beside the input
     # layers' deferred weight gradients: 3.376 vs 3.346 ms, two alternating pairs on one box; `--wgrad-scope sequence,embed`)
-    dp.enable_wgrad_overlap(not args.no_wgrad_overlap and args.workload in ("c2", "c2s"), args.wgrad_scope.split(","))
+    dp.enable_wgrad_overlap(not args.no_wgrad_overlap and (args.workload in ("c2", "c2s") or args.force_wgrad_overlap),
+                            "all" if args.wgrad_scope == "all" else args.wgrad_scope.split(","))
     # dW / db of the projections on the main stream wait until that stream has slack (the GNN stack's backward is done, the
     # sequence branch's is not): the hybrid encoders only
     dp.defer_weight_grads(not args.no_defer and (enc in ("hybridgnn", "hgt") or args.defer_all))
