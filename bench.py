@@ -603,6 +603,7 @@ def main():
                                    + ("hipGraph replay" if graphs is not None else "EAGER launches (see \"graph\")"),
                        "workload_id": args.workload, "per_gpu_subgraphs": N_SUB, "target_notes_per_subgraph": N_NOTES,
                        "objective": args.mt_strategy,
+                       "optimizer": f"clip 1.0 + AdamW(lr {args.lr:g}: the reference's 500-step linear warm-up to 5e-3 at step 50; weight decay 5e-3)",
                        **({"sampler": {"capacity_per_subgraph": sampler.cap, "pool": sampler.pool, "rows": sampler.num_nodes,
                                        "sources_dropped_by_capacity_or_pool": sampler.dropped()}} if sampler is not None else {}),
                        "sharding": ("every rank draws its own windows from the replicated corpus" if sampler is not None
